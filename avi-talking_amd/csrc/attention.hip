@@ -1,0 +1,190 @@
+// Multi-head attention, fp32 math, online softmax over 64-key tiles staged in LDS.
+//
+// Attention is 2.4 % of the path's FLOPs and must keep fp32-grade scores for the
+// 1e-3 parity gate, so it runs on the fp32 vector pipe rather than bf16 MFMA.
+// One workgroup = 4 waves = 32 query rows of one (batch, head); each wave owns 8 rows (16 / 4 at D = 256).
+//   QK^T : lane = key.   K tile rows padded to D+4 floats -> conflict-free ds_read_b128.
+//   PV   : lane = output dim (D/64 dims per lane; lanes >= D idle when D < 64).
+// Bias modes restate the reference masks analytically instead of materialising (H, T, T) tensors:
+//   1: -slope_h*|i-j|            (inferno TransformerMasking.py:80-98  init_alibi_biased_mask_future)
+//   2: j<=i ? -slope_h*((i-j)/period) : -inf   (models/faceformer.py:51-72 init_biased_mask)
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;   // keys per tile
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int D, int RPW>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ out,
+                                                         int H, int Tq, int Tk, int ldq, int ldk, int ldo, float scale,
+                                                         int bias_mode, const float* __restrict__ slopes, int period) {
+    constexpr int QB = 4 * RPW;                 // query rows per workgroup
+    constexpr int KS = D + 4;                   // padded K row stride (floats)
+    constexpr int DPL = D >= 64 ? D / 64 : 1;   // output dims per lane
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sK = reinterpret_cast<float*>(smem_raw);   // [KT][KS]
+    float* sV = sK + KT * KS;                         // [KT][D]
+    float* sQ = sV + KT * D;                          // [QB][D]
+    float* sP = sQ + QB * D;                          // [4][KT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int q0 = blockIdx.x * QB;
+    const float slope = (bias_mode != 0 && slopes) ? slopes[h] : 0.f;
+
+    // stage the 32 query rows (pre-scaled)
+    for (int i = tid; i < QB * (D / 4); i += 256) {
+        const int r = i / (D / 4), c4 = i - r * (D / 4);
+        const int qi = q0 + r;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi < Tq) val = *reinterpret_cast<const float4*>(q + ((long long)b * Tq + qi) * ldq + h * D + c4 * 4);
+        val.x *= scale; val.y *= scale; val.z *= scale; val.w *= scale;
+        *reinterpret_cast<float4*>(sQ + r * D + c4 * 4) = val;
+    }
+
+    float m[RPW], l[RPW], o[RPW][DPL];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        m[r] = NEG_BIG;
+        l[r] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) o[r][d] = 0.f;
+    }
+
+    // causal mode never needs keys past the block's last query row
+    int kend = Tk;
+    if (bias_mode == 2) {
+        const int lastq = (q0 + QB - 1 < Tq ? q0 + QB - 1 : Tq - 1);
+        kend = lastq + 1 < Tk ? lastq + 1 : Tk;
+    }
+
+    for (int j0 = 0; j0 < kend; j0 += KT) {
+        __syncthreads();  // previous tile fully consumed (also orders the sQ stores on the first pass)
+        for (int i = tid; i < KT * (D / 4); i += 256) {
+            const int r = i / (D / 4), c4 = i - r * (D / 4);
+            const int kj = j0 + r;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (kj < Tk) {
+                const long long off = ((long long)b * Tk + kj) * ldk + h * D + c4 * 4;
+                kv = *reinterpret_cast<const float4*>(k + off);
+                vv = *reinterpret_cast<const float4*>(v + off);
+            }
+            *reinterpret_cast<float4*>(sK + r * KS + c4 * 4) = kv;
+            *reinterpret_cast<float4*>(sV + r * D + c4 * 4) = vv;
+        }
+        __syncthreads();
+
+        const int j = j0 + lane;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int qi = q0 + wave * RPW + r;
+            // ---- score of key j for row qi
+            float s = 0.f;
+            const float* qr = sQ + (wave * RPW + r) * D;
+            const float* kr = sK + lane * KS;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(qr + d);
+                const float4 c = *reinterpret_cast<const float4*>(kr + d);
+                s = fmaf(a.x, c.x, s);
+                s = fmaf(a.y, c.y, s);
+                s = fmaf(a.z, c.z, s);
+                s = fmaf(a.w, c.w, s);
+            }
+            bool valid = j < Tk;
+            if (bias_mode == 1) {
+                const int dlt = qi > j ? qi - j : j - qi;
+                s -= slope * (float)dlt;
+            } else if (bias_mode == 2) {
+                valid = valid && (j <= qi);
+                s -= slope * (float)((qi - j) / period);
+            }
+            if (!valid) s = NEG_BIG;
+            // ---- online softmax
+            const float mt = wave_max(s);
+            const float mn = fmaxf(m[r], mt);
+            const float p = valid ? __expf(s - mn) : 0.f;
+            const float corr = __expf(m[r] - mn);
+            l[r] = l[r] * corr + wave_sum(p);
+            m[r] = mn;
+            sP[wave * KT + lane] = p;
+            __builtin_amdgcn_wave_barrier();
+            // ---- o = o*corr + p . V
+            float accd[DPL];
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) accd[d] = 0.f;
+            if (lane < D) {
+#pragma unroll 8
+                for (int jj = 0; jj < KT; jj += 4) {
+                    const float4 pv = *reinterpret_cast<const float4*>(sP + wave * KT + jj);
+#pragma unroll
+                    for (int d = 0; d < DPL; ++d) {
+                        const float* vr = sV + jj * D + lane + 64 * d;
+                        accd[d] = fmaf(pv.x, vr[0], accd[d]);
+                        accd[d] = fmaf(pv.y, vr[D], accd[d]);
+                        accd[d] = fmaf(pv.z, vr[2 * D], accd[d]);
+                        accd[d] = fmaf(pv.w, vr[3 * D], accd[d]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) o[r][d] = o[r][d] * corr + accd[d];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int qi = q0 + wave * RPW + r;
+        if (qi >= Tq || lane >= D) continue;
+        const float inv = l[r] > 0.f ? 1.f / l[r] : 0.f;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d)
+            out[((long long)b * Tq + qi) * ldo + h * D + lane + 64 * d] = o[r][d] * inv;
+    }
+}
+
+template <int D>
+int launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk,
+                     int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period,
+                     hipStream_t s) {
+    constexpr int RPW = D > 128 ? 4 : 8;  // D = 256: 16 query rows per workgroup keeps LDS under 160 KiB
+    constexpr int QB = 4 * RPW;
+    constexpr int smem = (KT * (D + 4) + KT * D + QB * D + 4 * KT) * (int)sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<D, RPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    dim3 grid((Tq + QB - 1) / QB, B * H);
+    hipLaunchKernelGGL((attention_kernel<D, RPW>), grid, dim3(256), smem, s, q, k, v, out, H, Tq, Tk, ldq, ldk, ldo, scale,
+                       bias_mode, slopes, period);
+    return avi_launch_status();
+}
+
+}  // namespace
+
+extern "C" int avi_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq,
+                             int Tk, int D, int ldq, int ldk, int ldo, float scale, int bias_mode,
+                             const float* slopes, int period, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return AVI_EINVAL;
+    if ((ldq & 3) || (ldk & 3) || bias_mode < 0 || bias_mode > 2) return AVI_EINVAL;
+    if (bias_mode != 0 && !slopes) return AVI_EINVAL;
+    if (bias_mode == 2 && period < 1) return AVI_EINVAL;
+    if ((long long)B * H > 65535) return AVI_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define AVI_ATT_CASE(DD) \
+    case DD: return launch_attention<DD>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
+    switch (D) {
+        AVI_ATT_CASE(16)
+        AVI_ATT_CASE(32)
+        AVI_ATT_CASE(64)
+        AVI_ATT_CASE(128)
+        AVI_ATT_CASE(256)
+        default: return AVI_EINVAL;
+    }
+#undef AVI_ATT_CASE
+}

@@ -1,0 +1,409 @@
+// HBM-bound kernels around the GEMMs: audio normalisation, conv layer 0 + GroupNorm + GELU,
+// resample + LayerNorm, LayerNorm, layout packing.  All fp32, 16-B accesses, channels-last.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ audio zero-mean / unit-var
+// stats[2*s + {0,1}] = sum, sum of squares (double) of clip s (s = 0 when joint).
+template <bool I16>
+__global__ void audio_stats_kernel(const void* __restrict__ pcm, int N, int joint, double* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const long long base = (long long)b * N;
+    double s = 0.0, q = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const float x = I16 ? (float)reinterpret_cast<const int16_t*>(pcm)[base + i]
+                            : reinterpret_cast<const float*>(pcm)[base + i];
+        s += x;
+        q += (double)x * x;
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) {
+        const int slot = joint ? 0 : b;
+        atomicAdd(&stats[2 * slot], s);
+        atomicAdd(&stats[2 * slot + 1], q);
+    }
+}
+
+template <bool I16>
+__global__ void audio_apply_kernel(const void* __restrict__ pcm, int N, int B, int joint, float eps,
+                                   const double* __restrict__ stats, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int slot = joint ? 0 : b;
+    const double cnt = joint ? (double)N * B : (double)N;
+    const double mean = stats[2 * slot] / cnt;
+    double var = stats[2 * slot + 1] / cnt - mean * mean;  // population variance (numpy .var())
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)mean, inv = (float)(1.0 / sqrt(var + (double)eps));
+    const long long base = (long long)b * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const float x = I16 ? (float)reinterpret_cast<const int16_t*>(pcm)[base + i]
+                            : reinterpret_cast<const float*>(pcm)[base + i];
+        out[base + i] = (x - fm) * inv;
+    }
+}
+
+// ------------------------------------------------------------------ conv layer 0 + GroupNorm + GELU
+// GroupNorm(512 groups over 512 channels) normalises each channel over time.  conv0 is linear in the
+// 10-sample window, so the per-channel mean / variance over t follow from the window's first and
+// second moments:  mean_c = w_c . S1 / T0,  E[y_c^2] = w_c^T S2 w_c / T0.  One pass over the audio
+// (65 sums per clip) replaces a full evaluation of the 512 x T0 activation.
+constexpr int C0 = 512, K0 = 10, ST0 = 5, NMOM = 65;  // 10 first + 55 second moments
+
+__global__ void conv0_moments_kernel(const float* __restrict__ x, int N, int T0, double* __restrict__ mom) {
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * N;
+    float s1[K0], s2[55];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) s1[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 55; ++j) s2[j] = 0.f;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T0; t += gridDim.x * blockDim.x) {
+        float w[K0];
+#pragma unroll
+        for (int j = 0; j < K0; ++j) w[j] = xb[t * ST0 + j];
+        int p = 0;
+#pragma unroll
+        for (int j = 0; j < K0; ++j) {
+            s1[j] += w[j];
+#pragma unroll
+            for (int i = j; i < K0; ++i) s2[p++] += w[j] * w[i];
+        }
+    }
+    double* mb = mom + (long long)b * NMOM;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+        const double v = wave_sum_d((double)s1[j]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&mb[j], v);
+    }
+#pragma unroll
+    for (int j = 0; j < 55; ++j) {
+        const double v = wave_sum_d((double)s2[j]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&mb[K0 + j], v);
+    }
+}
+
+__global__ void conv0_finalize_kernel(const double* __restrict__ mom, const float* __restrict__ w0,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int T0,
+                                      float eps, float* __restrict__ ss) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C0) return;
+    const double* mb = mom + (long long)b * NMOM;
+    double w[K0];
+#pragma unroll
+    for (int j = 0; j < K0; ++j) w[j] = (double)w0[c * K0 + j];
+    double m = 0.0, e2 = 0.0;
+    int p = 0;
+#pragma unroll
+    for (int j = 0; j < K0; ++j) {
+        m += w[j] * mb[j];
+#pragma unroll
+        for (int i = j; i < K0; ++i) {
+            const double v = w[j] * w[i] * mb[K0 + p++];
+            e2 += (i == j) ? v : 2.0 * v;
+        }
+    }
+    m /= T0;
+    double var = e2 / T0 - m * m;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+    ss[(long long)b * 2 * C0 + c] = (float)sc;
+    ss[(long long)b * 2 * C0 + C0 + c] = (float)((double)beta[c] - m * sc);
+}
+
+// y[b][t][c] = gelu(conv0(x)[t][c] * scale[b][c] + shift[b][c]);  block = 64 t x 512 c.
+constexpr int C0_TT = 64;
+__global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ x, int N, int T0,
+                                                           const float* __restrict__ w0,
+                                                           const float* __restrict__ ss, float* __restrict__ y) {
+    __shared__ float sx[C0_TT * ST0 + K0 + 2];
+    const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
+    const float* xb = x + (long long)b * N;
+    const int nload = C0_TT * ST0 + K0 - ST0;  // samples needed by 64 outputs
+    for (int i = threadIdx.x; i < nload; i += blockDim.x) {
+        const int s = t0 * ST0 + i;
+        sx[i] = s < N ? xb[s] : 0.f;
+    }
+    const int cg = threadIdx.x & 127;  // 4 channels per thread
+    const int tsub = threadIdx.x >> 7; // 2 time rows in flight
+    float w[4][K0], sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cg * 4 + q;
+#pragma unroll
+        for (int j = 0; j < K0; ++j) w[q][j] = w0[c * K0 + j];
+        sc[q] = ss[(long long)b * 2 * C0 + c];
+        sh[q] = ss[(long long)b * 2 * C0 + C0 + c];
+    }
+    __syncthreads();
+    for (int tt = tsub; tt < C0_TT; tt += 2) {
+        const int t = t0 + tt;
+        if (t >= T0) break;
+        float xv[K0];
+#pragma unroll
+        for (int j = 0; j < K0; ++j) xv[j] = sx[tt * ST0 + j];
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < K0; ++j) a = fmaf(w[q][j], xv[j], a);
+            o[q] = avi_gelu(a * sc[q] + sh[q]);
+        }
+        *reinterpret_cast<float4*>(y + ((long long)b * T0 + t) * C0 + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm helpers (one wave per row)
+template <int MAXV>  // MAXV float4 per lane held in registers: C <= 256*MAXV
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int rows, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = in + (long long)row * C;
+    const int nv = C >> 2;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < nv ? reinterpret_cast<const float4*>(x)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float* o = out + (long long)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gamma) g = reinterpret_cast<const float4*>(gamma)[idx];
+            if (beta) bb = reinterpret_cast<const float4*>(beta)[idx];
+            float4 r;
+            r.x = (v[i].x - mean) * rstd * g.x + bb.x;
+            r.y = (v[i].y - mean) * rstd * g.y + bb.y;
+            r.z = (v[i].z - mean) * rstd * g.z + bb.z;
+            r.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            reinterpret_cast<float4*>(o)[idx] = r;
+        }
+    }
+}
+
+// out[b][t] = LN( lerp(in[b][i0], in[b][i1]) ), align_corners=True index math of
+// torch upsample_linear1d: scale = (Tin-1)/(Tout-1), src = scale*t, i0 = (int)src, l1 = src - i0.
+template <int MAXV>
+__global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict__ in, int B, int Tin, int C, int Tout,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * Tout) return;
+    const int b = row / Tout, t = row - b * Tout;
+    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+    const float src = scale * (float)t;
+    int i0 = (int)src;
+    if (i0 > Tin - 1) i0 = Tin - 1;
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float l1 = src - (float)i0, l0 = 1.f - l1;
+    const float4* x0 = reinterpret_cast<const float4*>(in + ((long long)b * Tin + i0) * C);
+    const float4* x1 = reinterpret_cast<const float4*>(in + ((long long)b * Tin + i1) * C);
+    const int nv = C >> 2;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 a = x0[idx], c = x1[idx];
+            v[i] = make_float4(l0 * a.x + l1 * c.x, l0 * a.y + l1 * c.y, l0 * a.z + l1 * c.z, l0 * a.w + l1 * c.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    float4* o = reinterpret_cast<float4*>(out + (long long)row * C);
+    if (!gamma) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < nv) o[idx] = v[i];
+        }
+        return;
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + bb * bb + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[idx];
+            const float4 bb = reinterpret_cast<const float4*>(beta)[idx];
+            float4 r;
+            r.x = (v[i].x - mean) * rstd * g.x + bb.x;
+            r.y = (v[i].y - mean) * rstd * g.y + bb.y;
+            r.z = (v[i].z - mean) * rstd * g.z + bb.z;
+            r.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            o[idx] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ layout kernels
+__global__ void group_pad_pack_kernel(const float* __restrict__ h, int B, int T, int G, int Cg, int pad,
+                                      float* __restrict__ xg) {
+    const int Tp = T + 2 * pad, v4 = Cg >> 2;
+    const long long total = (long long)B * G * Tp * v4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % v4);
+        long long r = i / v4;
+        const int tp = (int)(r % Tp);
+        r /= Tp;
+        const int g = (int)(r % G), b = (int)(r / G);
+        const int t = tp - pad;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T)
+            val = *reinterpret_cast<const float4*>(h + ((long long)b * T + t) * (G * Cg) + g * Cg + cv * 4);
+        reinterpret_cast<float4*>(xg)[i] = val;
+    }
+}
+
+__global__ void pad_repeat_kernel(const float* __restrict__ in, int B, int T, int C, int rep, int padL, int padR,
+                                  int mode, float* __restrict__ out) {
+    const int To = padL + T * rep + padR, v4 = C >> 2;
+    const long long total = (long long)B * To * v4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % v4);
+        long long r = i / v4;
+        const int to = (int)(r % To), b = (int)(r / To);
+        int src = to - padL;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool valid = true;
+        if (src < 0) { valid = mode == 1; src = 0; }
+        else if (src >= T * rep) { valid = mode == 1; src = T * rep - 1; }
+        if (valid) val = *reinterpret_cast<const float4*>(in + ((long long)b * T + src / rep) * C + cv * 4);
+        reinterpret_cast<float4*>(out)[i] = val;
+    }
+}
+
+__global__ void add_rowbcast_kernel(const float* __restrict__ in, const float* __restrict__ add, int B, int T, int C,
+                                    float* __restrict__ out) {
+    const int v4 = C >> 2;
+    const long long total = (long long)B * T * v4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % v4);
+        const int b = (int)(i / ((long long)T * v4));
+        const float4 a = reinterpret_cast<const float4*>(in)[i];
+        const float4 d = reinterpret_cast<const float4*>(add + (long long)b * C)[cv];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+    }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 8192) {
+    long long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, int joint, float eps, float* out,
+                                   double* stats, void* stream) {
+    if (!pcm || !out || !stats || B <= 0 || N <= 0) return AVI_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s) != hipSuccess) return avi_launch_status();
+    dim3 grid(grid_for(N, 256, 64), B);
+    if (is_int16) {
+        hipLaunchKernelGGL(audio_stats_kernel<true>, grid, dim3(256), 0, s, pcm, N, joint, stats);
+        hipLaunchKernelGGL(audio_apply_kernel<true>, grid, dim3(256), 0, s, pcm, N, B, joint, eps, stats, out);
+    } else {
+        hipLaunchKernelGGL(audio_stats_kernel<false>, grid, dim3(256), 0, s, pcm, N, joint, stats);
+        hipLaunchKernelGGL(audio_apply_kernel<false>, grid, dim3(256), 0, s, pcm, N, B, joint, eps, stats, out);
+    }
+    return avi_launch_status();
+}
+
+extern "C" int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma,
+                                 const float* beta, float eps, float* y, double* moments, float* scale_shift,
+                                 void* stream) {
+    if (!x || !w0 || !gamma || !beta || !y || !moments || !scale_shift || B <= 0 || N < K0) return AVI_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T0 = (N - K0) / ST0 + 1;
+    if (hipMemsetAsync(moments, 0, sizeof(double) * NMOM * B, s) != hipSuccess) return avi_launch_status();
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3(grid_for(T0, 256, 32), B), dim3(256), 0, s, x, N, T0, moments);
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, w0, gamma, beta, T0, eps,
+                       scale_shift);
+    hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + C0_TT - 1) / C0_TT, B), dim3(256), 0, s, x, N, T0, w0,
+                       scale_shift, y);
+    return avi_launch_status();
+}
+
+extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const float* gamma,
+                                    const float* beta, float eps, float* out, void* stream) {
+    if (!in || !out || B <= 0 || Tin <= 0 || Tout <= 0 || (C & 3) || C > 1024) return AVI_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr)) return AVI_EINVAL;
+    const int rows = B * Tout;
+    hipLaunchKernelGGL(interp_ln_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       B, Tin, C, Tout, gamma, beta, eps, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                             float* out, void* stream) {
+    if (!in || !out || rows <= 0 || C <= 0 || (C & 3) || C > 4096) return AVI_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (C <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, out);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, float* xg, void* stream) {
+    if (!h || !xg || B <= 0 || T <= 0 || G <= 0 || Cg <= 0 || (Cg & 3) || pad < 0) return AVI_EINVAL;
+    const long long total = (long long)B * G * (T + 2 * pad) * (Cg >> 2);
+    hipLaunchKernelGGL(group_pad_pack_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h, B, T, G, Cg, pad, xg);
+    return avi_launch_status();
+}
+
+extern "C" int avi_pad_repeat(const float* in, int B, int T, int C, int rep, int padL, int padR, int mode,
+                              float* out, void* stream) {
+    if (!in || !out || B <= 0 || T <= 0 || C <= 0 || (C & 3) || rep < 1 || padL < 0 || padR < 0) return AVI_EINVAL;
+    const long long total = (long long)B * (padL + (long long)T * rep + padR) * (C >> 2);
+    hipLaunchKernelGGL(pad_repeat_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       B, T, C, rep, padL, padR, mode, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_add_rowbcast(const float* in, const float* add, int B, int T, int C, float* out, void* stream) {
+    if (!in || !add || !out || B <= 0 || T <= 0 || C <= 0 || (C & 3)) return AVI_EINVAL;
+    const long long total = (long long)B * T * (C >> 2);
+    hipLaunchKernelGGL(add_rowbcast_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, add, B, T, C, out);
+    return avi_launch_status();
+}

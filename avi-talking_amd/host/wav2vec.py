@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference audio encoder: ``models/lib/wav2vec.py`` ``Wav2Vec2Model``
+(and its EMOTE twin ``inferno/models/temporal/AudioEncoders.py`` ``Wav2Vec2ModelResampled``).
+
+Same call signature and result object as the reference wrapper (models/lib/wav2vec.py:80-156);
+the arithmetic runs in the HIP kernels behind the C ABI.  Weights come from a HF-named
+``state_dict`` (``Wav2Vec2Model.from_state_dict``), so a real wav2vec2-base checkpoint loads as is.
+
+Inference only: dropout/SpecAugment/LayerDrop are training-time branches of the reference
+(models/lib/wav2vec.py:123-141) and are not taken in ``eval()``.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from .. import ops
+
+CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
+CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
+HIDDEN, HEADS, LAYERS, POS_K, POS_G = 768, 12, 12, 128, 16
+
+
+def conv_out_lengths(n):
+    out = []
+    for k, s in zip(CONV_KERNEL, CONV_STRIDE):
+        n = (n - k) // s + 1
+        out.append(n)
+    return out
+
+
+class Wav2Vec2Model:
+    """wav2vec2-base with 50->25 Hz linear resampling between the CNN and the transformer."""
+
+    def __init__(self, state_dict, device="cuda", prec=ops.PREC_BF16X3, length_mode="int"):
+        self.device = torch.device(device)
+        self.prec = prec
+        self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
+        w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
+             if v.is_floating_point()}
+        fe = "feature_extractor.conv_layers."
+        self.w0 = w[fe + "0.conv.weight"].reshape(512, 10).contiguous()
+        self.gn_g = w[fe + "0.layer_norm.weight"]
+        self.gn_b = w[fe + "0.layer_norm.bias"]
+        # Conv1d weight (Cout, Cin, k) -> tap-major [Cout][k*Cin] for the overlapping-row GEMM
+        self.convs = [ops.PackedWeight(w[fe + f"{i}.conv.weight"].permute(0, 2, 1).reshape(512, -1))
+                      for i in range(1, 7)]
+        self.fp_g = w["feature_projection.layer_norm.weight"]
+        self.fp_b = w["feature_projection.layer_norm.bias"]
+        self.proj = ops.PackedWeight(w["feature_projection.projection.weight"], w["feature_projection.projection.bias"])
+        # pos-conv: fold weight-norm (dim=2), regroup to [G][64 (48 used)][k*48]
+        g_ = w["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
+        v_ = w["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+        wpc = g_ * v_ / v_.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()            # (768, 48, 128)
+        cg = HIDDEN // POS_G
+        wg = wpc.view(POS_G, cg, cg, POS_K).permute(0, 1, 3, 2).reshape(POS_G, cg, POS_K * cg)
+        wpad = torch.zeros((POS_G, 64, POS_K * cg), device=self.device)
+        wpad[:, :cg] = wg
+        self.pos = ops.PackedWeight(wpad.reshape(POS_G * 64, POS_K * cg))
+        self.pos_bias = w["encoder.pos_conv_embed.conv.bias"]
+        self.enc_g = w["encoder.layer_norm.weight"]
+        self.enc_b = w["encoder.layer_norm.bias"]
+        self.layers = []
+        for i in range(LAYERS):
+            p = f"encoder.layers.{i}."
+            a = p + "attention."
+            qkv_w = torch.cat([w[a + "q_proj.weight"], w[a + "k_proj.weight"], w[a + "v_proj.weight"]], 0)
+            qkv_b = torch.cat([w[a + "q_proj.bias"], w[a + "k_proj.bias"], w[a + "v_proj.bias"]], 0)
+            self.layers.append(SimpleNamespace(
+                qkv=ops.PackedWeight(qkv_w, qkv_b),
+                out=ops.PackedWeight(w[a + "out_proj.weight"], w[a + "out_proj.bias"]),
+                ln1=(w[p + "layer_norm.weight"], w[p + "layer_norm.bias"]),
+                ff1=ops.PackedWeight(w[p + "feed_forward.intermediate_dense.weight"],
+                                     w[p + "feed_forward.intermediate_dense.bias"]),
+                ff2=ops.PackedWeight(w[p + "feed_forward.output_dense.weight"],
+                                     w[p + "feed_forward.output_dense.bias"]),
+                ln2=(w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"])))
+
+    @classmethod
+    def from_state_dict(cls, state_dict, **kw):
+        return cls(state_dict, **kw)
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ stages
+    def feature_extractor(self, input_values):
+        """(B, N) -> channels-last (B, L, 512) (the reference returns (B, 512, L))."""
+        h = ops.conv0_gn_gelu(input_values, self.w0, self.gn_g, self.gn_b)
+        for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
+            h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
+        return h
+
+    def output_length(self, L50, frame_num=None):
+        if frame_num is not None:
+            return int(frame_num)
+        seq_len = L50 / 50.0
+        return int(seq_len * 25) if self.length_mode == "int" else int(math.ceil(seq_len * 25))
+
+    def encoder(self, hp):
+        B, T, _ = hp.shape
+        cg = HIDDEN // POS_G
+        xg = ops.group_pad_pack(hp, POS_G, POS_K // 2)
+        h = torch.empty_like(hp)
+        Tp = T + POS_K
+        ops.gemm_raw(A=xg.data_ptr(), lda=cg, Whi=self.pos.hi.data_ptr(), Wlo=self.pos.lo.data_ptr(),
+                     C_=h.data_ptr(), ldc=HIDDEN, M=T, N=cg, K=POS_K * cg, bias=self.pos_bias.data_ptr(),
+                     R=hp.data_ptr(), ldr=HIDDEN, act=ops.ACT_GELU, prec=self.prec, batch=B * POS_G, z_inner=POS_G,
+                     sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
+                     sR=(T * HIDDEN, cg))
+        h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
+        d = HIDDEN // HEADS
+        for ly in self.layers:
+            qkv = ops.linear(h, ly.qkv, prec=self.prec)                               # (B,T,2304)
+            q, k, v = qkv[..., :HIDDEN], qkv[..., HIDDEN:2 * HIDDEN], qkv[..., 2 * HIDDEN:]
+            att = ops.attention(q, k, v, HEADS, d, 3 * HIDDEN, 3 * HIDDEN, T, T, B, d ** -0.5)
+            h = ops.linear(att, ly.out, residual=h, prec=self.prec)
+            h = ops.layernorm(h, *ly.ln1, out=h)
+            f = ops.linear(h, ly.ff1, act=ops.ACT_GELU, prec=self.prec)
+            h = ops.linear(f, ly.ff2, residual=h, prec=self.prec)
+            h = ops.layernorm(h, *ly.ln2, out=h)
+        return h
+
+    def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, frame_num=None):
+        """models/lib/wav2vec.py:80-156.  ``attention_mask`` (padding) is not supported on the
+        hot path (the reference callers never pass one: models/faceformer.py:330,673)."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not used on the reference hot path")
+        if input_values.dim() != 2:
+            raise ValueError("input_values must be (B, N)")
+        x = input_values.to(self.device, torch.float32).contiguous()
+        feats = self.feature_extractor(x)
+        T = self.output_length(feats.shape[1], frame_num)
+        h25 = ops.interp_layernorm(feats, T, self.fp_g, self.fp_b)
+        hp = ops.linear(h25, self.proj, prec=self.prec)
+        h = self.encoder(hp)
+        out = SimpleNamespace(last_hidden_state=h, hidden_states=None, attentions=None,
+                              extract_features=feats)
+        return out if (return_dict is None or return_dict) else (h,)
+
+    __call__ = forward

@@ -1,0 +1,92 @@
+"""ctypes binding of ``libavi_talking_hip.so`` (the C ABI in ``include/avi_talking.h``).
+
+torch is used here only for device memory and the current HIP stream: every wrapper passes
+``tensor.data_ptr()`` and ``torch.cuda.current_stream().cuda_stream`` across the C ABI.
+There is no CPU fallback: a missing library or a failed launch raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavi_talking_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_LRELU02, ACT_RELU, ACT_SILU = 0, 1, 2, 3, 4
+PREC_BF16, PREC_BF16X3 = 1, 3
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class AviGemm(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("lda", _ll), ("sAo", _ll), ("sAi", _ll),
+        ("Whi", _vp), ("Wlo", _vp), ("sWo", _ll), ("sWi", _ll),
+        ("C", _vp), ("ldc", _ll), ("sCo", _ll), ("sCi", _ll),
+        ("bias", _vp), ("sBo", _ll), ("sBi", _ll),
+        ("R", _vp), ("ldr", _ll), ("sRo", _ll), ("sRi", _ll),
+        ("scale", _vp), ("shift", _vp),
+        ("M", _i), ("N", _i), ("K", _i),
+        ("batch", _i), ("z_inner", _i),
+        ("act", _i), ("prec", _i),
+    ]
+
+
+# name -> argtypes; every function returns int status.  Kept in one table so the CPU-side test can
+# check that the library exports every symbol the header declares.
+SIGNATURES = {
+    "avi_gemm": [C.POINTER(AviGemm), _vp],
+    "avi_pack_weight_split": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "avi_audio_normalize": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "avi_conv0_gn_gelu": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python avi-talking_amd/build.py` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.avi_version.restype = C.c_char_p
+        lib.avi_version.argtypes = []
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _i
+        _lib = lib
+    return _lib
+
+
+def version():
+    return load().avi_version().decode()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("avi_talking_amd: tensors must live on the GPU (no CPU fallback)")

@@ -1,0 +1,197 @@
+"""Tensor-level wrappers over the C ABI (``lib.py``): shape checks on the host, then one launch.
+
+Operand shapes are validated here, before the kernel is launched, so that a mismatch raises in
+Python instead of faulting on the GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_SILU, PREC_BF16, PREC_BF16X3  # noqa: F401
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous fp32, got {t.dtype} contiguous={t.is_contiguous()}")
+    L.require_gpu(t)
+    return t
+
+
+class PackedWeight:
+    """A Linear/Conv weight [N][K] pre-split into bf16 hi/lo parts, rows padded for the GEMM tiles."""
+
+    def __init__(self, w2d, bias=None):
+        w2d = _f32c(w2d.contiguous(), "weight")
+        self.N, self.K = w2d.shape
+        if self.K % 64:
+            raise ValueError(f"K={self.K} must be a multiple of 64")
+        self.N_pad = 64 if self.N <= 64 else (self.N + 127) // 128 * 128
+        self.hi = torch.empty((self.N_pad, self.K), dtype=torch.int16, device=w2d.device)
+        self.lo = torch.empty_like(self.hi)
+        L.check(L.load().avi_pack_weight_split(w2d.data_ptr(), self.N, self.K, self.N_pad, self.hi.data_ptr(),
+                                               self.lo.data_ptr(), L.stream_ptr()), "avi_pack_weight_split")
+        self.bias = None if bias is None else _f32c(bias.contiguous(), "bias")
+
+    @property
+    def nbytes(self):
+        return self.hi.numel() * 4
+
+
+def gemm_raw(*, A, lda, Whi, Wlo, C_, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
+             prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0)):
+    """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets)."""
+    g = L.AviGemm()
+    g.A, g.lda, g.sAo, g.sAi = A, lda, sA[0], sA[1]
+    g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
+    g.C, g.ldc, g.sCo, g.sCi = C_, ldc, sC[0], sC[1]
+    g.bias, g.sBo, g.sBi = bias or None, sB[0], sB[1]
+    g.R, g.ldr, g.sRo, g.sRi = R or None, ldr, sR[0], sR[1]
+    g.scale, g.shift = scale or None, shift or None
+    g.M, g.N, g.K = M, N, K
+    g.batch, g.z_inner = batch, z_inner
+    g.act, g.prec = act, prec
+    L.check(L.load().avi_gemm(C.byref(g), L.stream_ptr()), "avi_gemm")
+
+
+def linear(x, pw, out=None, act=ACT_NONE, residual=None, prec=PREC_BF16X3, scale=None, shift=None):
+    """out[..., N] = affine(act(x[..., K] @ W^T + b)) + residual."""
+    x = _f32c(x, "x")
+    K = x.shape[-1]
+    if K != pw.K:
+        raise ValueError(f"linear: x has K={K}, weight has K={pw.K}")
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (pw.N,), dtype=torch.float32, device=x.device)
+    _f32c(out, "out")
+    if out.numel() != M * pw.N:
+        raise ValueError("linear: bad out shape")
+    if residual is not None:
+        _f32c(residual, "residual")
+        if residual.numel() != M * pw.N:
+            raise ValueError("linear: bad residual shape")
+    gemm_raw(A=x.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=out.data_ptr(), ldc=pw.N, M=M,
+             N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, scale=L.ptr(scale), shift=L.ptr(shift),
+             act=act, prec=prec)
+    return out
+
+
+def conv1d_cl(x, pw, ksize, stride, out=None, act=ACT_NONE, prec=PREC_BF16X3, scale=None, shift=None,
+              out_rows=None, out_row_stride=None, out_offset=0):
+    """Channels-last Conv1d without padding as an overlapping-row GEMM.
+
+    x [B][Tin][Cin]; weight packed as [Cout][k*Cin] (tap-major); out [B][Tout][Cout] with
+    Tout = (Tin-k)//stride+1.  ``out_rows``/``out_row_stride``/``out_offset`` let the caller
+    interleave rows into a larger buffer (ConvTranspose1d phases).
+    """
+    x = _f32c(x, "x")
+    B, Tin, Cin = x.shape
+    if pw.K != ksize * Cin:
+        raise ValueError(f"conv1d_cl: weight K={pw.K} != k*Cin={ksize * Cin}")
+    Tout = (Tin - ksize) // stride + 1
+    if Tout <= 0:
+        raise ValueError("conv1d_cl: input shorter than the kernel")
+    if out is None:
+        out = torch.empty((B, Tout, pw.N), dtype=torch.float32, device=x.device)
+    _f32c(out, "out")
+    rows = Tout if out_rows is None else out_rows
+    ldc = pw.N if out_row_stride is None else out_row_stride
+    per_b = out.numel() // B
+    if out_offset + (rows - 1) * ldc + pw.N > per_b:
+        raise ValueError("conv1d_cl: output rows exceed the out buffer")
+    gemm_raw(A=x.data_ptr(), lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+             C_=out.data_ptr() + 4 * out_offset, ldc=ldc, M=rows, N=pw.N, K=pw.K, bias=L.ptr(pw.bias),
+             scale=L.ptr(scale), shift=L.ptr(shift), act=act, prec=prec, batch=B, z_inner=1,
+             sA=(Tin * Cin, 0), sC=(per_b, 0))
+    return out
+
+
+def audio_normalize(pcm, joint=False, eps=1e-7):
+    """int16 or fp32 [B][N] -> zero-mean/unit-variance fp32 [B][N] (per clip, or jointly)."""
+    L.require_gpu(pcm)
+    if pcm.dtype not in (torch.int16, torch.float32) or not pcm.is_contiguous() or pcm.dim() != 2:
+        raise ValueError("audio_normalize: expected contiguous int16/fp32 [B][N]")
+    B, N = pcm.shape
+    out = torch.empty((B, N), dtype=torch.float32, device=pcm.device)
+    stats = torch.empty((2 * B,), dtype=torch.float64, device=pcm.device)
+    L.check(L.load().avi_audio_normalize(pcm.data_ptr(), int(pcm.dtype == torch.int16), B, N, int(joint), eps,
+                                         out.data_ptr(), stats.data_ptr(), L.stream_ptr()), "avi_audio_normalize")
+    return out
+
+
+def conv0_gn_gelu(x, w0, gamma, beta, eps=1e-5, out=None):
+    x = _f32c(x, "x")
+    B, N = x.shape
+    if tuple(w0.shape) != (512, 10):
+        raise ValueError("conv0: weight must be [512][10]")
+    T0 = (N - 10) // 5 + 1
+    if out is None:
+        out = torch.empty((B, T0, 512), dtype=torch.float32, device=x.device)
+    mom = torch.empty((65 * B,), dtype=torch.float64, device=x.device)
+    ss = torch.empty((1024 * B,), dtype=torch.float32, device=x.device)
+    L.check(L.load().avi_conv0_gn_gelu(x.data_ptr(), B, N, _f32c(w0, "w0").data_ptr(), gamma.data_ptr(),
+                                       beta.data_ptr(), eps, out.data_ptr(), mom.data_ptr(), ss.data_ptr(),
+                                       L.stream_ptr()), "avi_conv0_gn_gelu")
+    return out
+
+
+def interp_layernorm(x, Tout, gamma=None, beta=None, eps=1e-5):
+    x = _f32c(x, "x")
+    B, Tin, Cc = x.shape
+    out = torch.empty((B, Tout, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.load().avi_interp_layernorm(x.data_ptr(), B, Tin, Cc, Tout, L.ptr(gamma), L.ptr(beta), eps,
+                                          out.data_ptr(), L.stream_ptr()), "avi_interp_layernorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().avi_layernorm(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps, out.data_ptr(),
+                                   L.stream_ptr()), "avi_layernorm")
+    return out
+
+
+def group_pad_pack(h, G, pad):
+    h = _f32c(h, "h")
+    B, T, Cc = h.shape
+    Cg = Cc // G
+    out = torch.empty((B, G, T + 2 * pad, Cg), dtype=torch.float32, device=h.device)
+    L.check(L.load().avi_group_pad_pack(h.data_ptr(), B, T, G, Cg, pad, out.data_ptr(), L.stream_ptr()),
+            "avi_group_pad_pack")
+    return out
+
+
+def pad_repeat(x, rep=1, padL=0, padR=0, mode=0):
+    x = _f32c(x, "x")
+    B, T, Cc = x.shape
+    out = torch.empty((B, padL + T * rep + padR, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.load().avi_pad_repeat(x.data_ptr(), B, T, Cc, rep, padL, padR, mode, out.data_ptr(), L.stream_ptr()),
+            "avi_pad_repeat")
+    return out
+
+
+def add_rowbcast(x, add):
+    x = _f32c(x, "x")
+    add = _f32c(add, "add")
+    B, T, Cc = x.shape
+    if add.numel() != B * Cc:
+        raise ValueError("add_rowbcast: add must be [B][C]")
+    out = torch.empty_like(x)
+    L.check(L.load().avi_add_rowbcast(x.data_ptr(), add.data_ptr(), B, T, Cc, out.data_ptr(), L.stream_ptr()),
+            "avi_add_rowbcast")
+    return out
+
+
+def attention(q, k, v, H, D, ldq, ldk, Tq, Tk, B, scale, bias_mode=0, slopes=None, period=1, out=None):
+    """q/k/v are base tensors (possibly views into one packed QKV buffer); ldq/ldk are row strides."""
+    L.require_gpu(q, k, v)
+    if out is None:
+        out = torch.empty((B, Tq, H * D), dtype=torch.float32, device=q.device)
+    L.check(L.load().avi_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Tq, Tk, D, ldq,
+                                   ldk, H * D, scale, bias_mode, L.ptr(slopes), period, L.stream_ptr()),
+            "avi_attention")
+    return out

@@ -1,0 +1,125 @@
+/*
+ * avi_talking.h -- C ABI of libavi_talking_hip.so (MI355X / gfx950).
+ *
+ * The reference (sunyasheng/AVI-Talking) is pure Python over torch; it has no FFI for this
+ * path.  Its boundary is a set of Python call signatures.  This header is
+ * the C-ABI a binding for those call sites targets: plain device pointers, sizes and a
+ * hipStream_t, no torch types.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless a parameter is documented as host;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *     nothing allocates, frees or synchronises, so every call is hipGraph-capturable;
+ *   - activations are fp32, row-major, "channels last" ([batch][time][channel]);
+ *   - GEMM weights are stored [N_pad][K] in bf16 as a hi part and (optionally) a lo part
+ *     (w = hi + lo to ~2^-17 relative), produced by avi_pack_weight_split();
+ *   - return value: 0 on success, a negative AVI_E* code on a bad argument, or the positive
+ *     hipError_t of a failed launch.
+ */
+#ifndef AVI_TALKING_H
+#define AVI_TALKING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVI_OK 0
+#define AVI_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define AVI_ENOSPC (-2)   /* workspace too small */
+
+/* activation codes for AviGemm.act */
+#define AVI_ACT_NONE 0
+#define AVI_ACT_GELU 1    /* exact erf GELU (torch.nn.functional.gelu default) */
+#define AVI_ACT_LRELU02 2 /* LeakyReLU(0.2) (L2lMotionPrior.py:376,389) */
+#define AVI_ACT_RELU 3    /* nn.TransformerDecoderLayer default (models/faceformer.py:148) */
+#define AVI_ACT_SILU 4
+
+/* precision codes: how fp32 operands are fed to the bf16 matrix cores */
+#define AVI_PREC_BF16 1   /* x,w rounded to bf16; 1 MFMA per product; ~4e-3 relative */
+#define AVI_PREC_BF16X3 3 /* x=xh+xl, w=wh+wl; xh*wh + xh*wl + xl*wh; ~1e-5 relative (parity mode) */
+
+const char* avi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched strided GEMM with fused epilogue -- the dense contraction under every Linear / Conv1d
+ * on the path:
+ *     C[z][m][n] = affine( act( sum_k A[z][m*lda + k] * W[z][n][k] + bias[z][n] ) ) + R[z][m][n]
+ * A rows may overlap (lda < K): a channels-last Conv1d(C_in, C_out, k, stride s) is exactly this
+ * GEMM with lda = s*C_in, K = k*C_in (HF Wav2Vec2 conv layers 1-6, models/lib/wav2vec.py:97;
+ * FLINT convs, L2lMotionPrior.py:370-392,419-424).  Linear layers use lda = K.
+ * Batch index z = zo*z_inner + zi; every operand has an outer and an inner batch stride
+ * (in elements), which covers grouped convolution (pos-conv, groups = z_inner).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct AviGemm {
+    const float* A;       long long lda, sAo, sAi;
+    const uint16_t* Whi;  /* bf16 [N_pad][K]; N_pad = 64 if N <= 64, else N rounded up to 128 */
+    const uint16_t* Wlo;  /* bf16 lo part; required when prec == AVI_PREC_BF16X3 */
+    long long sWo, sWi;
+    float* C;             long long ldc, sCo, sCi;
+    const float* bias;    long long sBo, sBi;     /* [N] or NULL */
+    const float* R;       long long ldr, sRo, sRi; /* residual, or NULL */
+    const float* scale;   const float* shift;      /* post-activation per-n affine (BatchNorm eval), or NULL */
+    int M, N, K;          /* K % 64 == 0 */
+    int batch, z_inner;   /* batch >= 1, z_inner >= 1, batch % z_inner == 0 */
+    int act, prec;
+} AviGemm;
+int avi_gemm(const AviGemm* g, void* stream);
+
+/* fp32 [N][K] -> bf16 hi/lo [N_pad][K] (rows N..N_pad-1 zero).  lo may be NULL. */
+int avi_pack_weight_split(const float* W, int N, int K, int N_pad, uint16_t* hi, uint16_t* lo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Audio front end.  Replaces HF Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm as called from
+ * inferno/models/temporal/AudioEncoders.py:170-178 (joint over the batch) and
+ * dataset/data_loader.py:289-290 (per clip), and conv layer 0 + GroupNorm + GELU of the HF
+ * feature encoder (models/lib/wav2vec.py:97).
+ * ---------------------------------------------------------------------------------------- */
+/* pcm: int16 [B][N] (is_int16 != 0) or fp32 [B][N]; out fp32 [B][N]; stats: scratch >= 2*B doubles */
+int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, int joint, float eps,
+                        float* out, double* stats, void* stream);
+/* x [B][N] -> y [B][T0][512] = GELU(GroupNorm_512(Conv1d(1,512,10,stride 5)(x))), T0 = (N-10)/5+1.
+ * w0 [512][10], gamma/beta [512]; moments: scratch >= 65*B doubles; scale_shift: scratch >= 1024*B floats. */
+int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
+                      float eps, float* y, double* moments, float* scale_shift, void* stream);
+
+/* 50->25 Hz resample (F.interpolate linear, align_corners=True; models/lib/wav2vec.py:67-73) fused
+ * with LayerNorm(C) of the feature projection (HF Wav2Vec2FeatureProjection).
+ * in [B][Tin][C] -> out [B][Tout][C]; gamma/beta may be NULL (interpolation only). */
+int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const float* gamma,
+                         const float* beta, float eps, float* out, void* stream);
+
+/* row LayerNorm: out[r] = LN(in[r]) * gamma + beta, rows x C.  in == out allowed. */
+int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                  float* out, void* stream);
+
+/* pos-conv input packing: h [B][T][G*Cg] -> xg [B][G][T+2*pad][Cg], zero padded (pad = 64, Cg = 48). */
+int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, float* xg, void* stream);
+
+/* time-axis padding / repetition: in [B][T][C] -> out [B][padL + T*rep + padR][C];
+ * mode 0 zeros, 1 replicate edge rows (Conv1d padding_mode='replicate', L2lMotionPrior.py:387). */
+int avi_pad_repeat(const float* in, int B, int T, int C, int rep, int padL, int padR, int mode,
+                   float* out, void* stream);
+
+/* out[b][t][c] = in[b][t][c] + add[b][c]  (EMOTE style_op "add", FaceFormerDecoder.py:667-668) */
+int avi_add_rowbcast(const float* in, const float* add, int B, int T, int C, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention over packed projections (fp32 math, online softmax).
+ *   q [B][Tq][ldq], k/v [B][Tk][ldk] with head h at column h*D; out [B][Tq][ldo].
+ *   bias_mode: 0 none (HF wav2vec2 eager attention; EMOTE bert_decoder, temporal_bias none)
+ *              1 ALiBi "future": -slope_h*|i-j|   (TransformerMasking.py:80-98, FLINT decoder)
+ *              2 FaceFormer causal: j<=i: -slope_h*floor((i-j)/period), j>i: -inf
+ *                (models/faceformer.py:51-72)
+ *   slopes [H] (device) for modes 1,2.  scale multiplies q.k (1/sqrt(D)).
+ * ---------------------------------------------------------------------------------------- */
+int avi_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk,
+                  int D, int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes,
+                  int period, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVI_TALKING_H */

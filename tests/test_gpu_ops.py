@@ -1,0 +1,155 @@
+"""GPU parity of every C-ABI op against plain torch fp32 on the CPU (same seeded inputs).
+
+Tolerances: the bf16x3 GEMM mode (parity mode) carries ~1e-5 relative error per product sum;
+bf16 mode ~4e-3 relative.  Elementwise/LN/attention kernels are fp32 and must agree to ~1e-5.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 1536), (128, 768, 512), (1000, 48, 6144), (77, 53, 1280),
+                                    (515, 2304, 768), (64, 128, 64)])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_linear(gpu, M, N, K, prec):
+    from avi_talking_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    out = ops.linear(x.to(gpu), pw, act=ops.ACT_GELU, residual=r.to(gpu), prec=prec).cpu().double()
+    err = (out - ref).abs().max().item()
+    tol = 2e-5 * math.sqrt(K / 64) if prec == 3 else 3e-2
+    assert err < tol, (err, tol)
+
+
+def test_linear_affine_noresidual(gpu):
+    from avi_talking_amd import ops
+    M, N, K = 200, 256, 1280
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    sc, sh = _rand((N,), 5) * 0.1 + 1, _rand((N,), 6)
+    ref = F.leaky_relu(F.linear(x, w, b), 0.2) * sc + sh
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    out = ops.linear(x.to(gpu), pw, act=ops.ACT_LRELU02, scale=sc.to(gpu), shift=sh.to(gpu)).cpu()
+    assert (out - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("k,s,Tin", [(3, 2, 1001), (2, 2, 400), (5, 1, 70)])
+def test_conv1d_cl(gpu, k, s, Tin):
+    from avi_talking_amd import ops
+    B, C = 3, 512 if k < 5 else 256
+    x = _rand((B, Tin, C), 7)
+    w = _rand((C, C, k), 8, (C * k) ** -0.5)
+    ref = F.gelu(F.conv1d(x.transpose(1, 2), w, stride=s)).transpose(1, 2)
+    pw = ops.PackedWeight(w.permute(0, 2, 1).reshape(C, -1).to(gpu))
+    out = ops.conv1d_cl(x.to(gpu), pw, k, s, act=ops.ACT_GELU).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 5e-5
+
+
+def test_conv0_gn_gelu(gpu):
+    from avi_talking_amd import ops
+    B, N = 3, 16000 + 7
+    x = _rand((B, N), 9) + 0.05
+    w0 = _rand((512, 1, 10), 10, 0.6)
+    g, b = _rand((512,), 11) * 0.1 + 1, _rand((512,), 12) * 0.1
+    ref = F.gelu(F.group_norm(F.conv1d(x[:, None], w0, stride=5), 512, g, b, 1e-5)).transpose(1, 2)
+    out = ops.conv0_gn_gelu(x.to(gpu), w0.reshape(512, 10).contiguous().to(gpu), g.to(gpu), b.to(gpu)).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("joint", [False, True])
+@pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
+def test_audio_normalize(gpu, joint, dtype):
+    from avi_talking_amd import ops
+    x = (_rand((4, 20000), 13) * 3000 + 100)
+    x = x.to(dtype)
+    xf = x.float()
+    if joint:
+        ref = (xf - xf.mean()) / torch.sqrt(xf.var(unbiased=False) + 1e-7)
+    else:
+        ref = (xf - xf.mean(-1, keepdim=True)) / torch.sqrt(xf.var(-1, unbiased=False, keepdim=True) + 1e-7)
+    out = ops.audio_normalize(x.to(gpu), joint=joint).cpu()
+    assert (out - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("Tin,Tout", [(499, 250), (199, 100), (99, 49), (50, 50), (7, 1)])
+def test_interp_layernorm(gpu, Tin, Tout):
+    from avi_talking_amd import ops
+    x = _rand((2, Tin, 512), 14)
+    g, b = _rand((512,), 15) * 0.1 + 1, _rand((512,), 16) * 0.1
+    it = F.interpolate(x.transpose(1, 2), size=Tout, align_corners=True, mode="linear").transpose(1, 2)
+    ref = F.layer_norm(it, (512,), g, b, 1e-5)
+    out = ops.interp_layernorm(x.to(gpu), Tout, g.to(gpu), b.to(gpu)).cpu()
+    assert (out - ref).abs().max().item() < 2e-5
+    out2 = ops.interp_layernorm(x.to(gpu), Tout).cpu()
+    assert (out2 - it).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("C", [64, 128, 768, 1024, 2048, 4096])
+def test_layernorm(gpu, C):
+    from avi_talking_amd import ops
+    x = _rand((37, C), 17) * 2 + 0.5
+    g, b = _rand((C,), 18) * 0.1 + 1, _rand((C,), 19) * 0.1
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    out = ops.layernorm(x.to(gpu), g.to(gpu), b.to(gpu)).cpu()
+    assert (out - ref).abs().max().item() < 2e-5
+
+
+def _slopes(n):
+    def p2(n):
+        start = 2 ** (-2 ** -(math.log2(n) - 3))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n).is_integer():
+        return p2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return p2(c) + _slopes(2 * c)[0::2][:n - c]
+
+
+@pytest.mark.parametrize("H,D,T,mode", [(12, 64, 250, 0), (8, 16, 97, 0), (8, 32, 256, 1), (4, 16, 130, 2),
+                                        (4, 256, 70, 2), (2, 128, 65, 0)])
+def test_attention(gpu, H, D, T, mode):
+    from avi_talking_amd import ops
+    B = 2
+    qkv = _rand((B, T, 3 * H * D), 20)
+    q, k, v = [t.reshape(B, T, H, D).transpose(1, 2) for t in qkv.split(H * D, -1)]
+    s = torch.matmul(q, k.transpose(2, 3)) * D ** -0.5
+    slopes = torch.tensor(_slopes(H))
+    i = torch.arange(T)[:, None]
+    j = torch.arange(T)[None, :]
+    period = 30
+    if mode == 1:
+        s = s - slopes[None, :, None, None] * (i - j).abs()[None, None]
+    elif mode == 2:
+        bias = -slopes[None, :, None, None] * ((i - j) // period)[None, None].float()
+        s = (s + bias).masked_fill((j > i)[None, None], float("-inf"))
+    ref = torch.matmul(torch.softmax(s, -1), v).transpose(1, 2).reshape(B, T, H * D)
+    dq = qkv.to(gpu)
+    out = ops.attention(dq[..., :H * D], dq[..., H * D:2 * H * D], dq[..., 2 * H * D:], H, D, 3 * H * D, 3 * H * D,
+                        T, T, B, D ** -0.5, bias_mode=mode, slopes=slopes.to(gpu), period=period).cpu()
+    assert (out - ref).abs().max().item() < 2e-5
+
+
+def test_pad_repeat_and_pack(gpu):
+    from avi_talking_amd import ops
+    x = _rand((2, 5, 8), 21)
+    out = ops.pad_repeat(x.to(gpu), rep=2, padL=2, padR=2, mode=1).cpu()
+    ref = F.pad(x.repeat_interleave(2, 1).transpose(1, 2), (2, 2), mode="replicate").transpose(1, 2)
+    assert torch.equal(out, ref)
+    out0 = ops.pad_repeat(x.to(gpu), rep=1, padL=1, padR=3, mode=0).cpu()
+    assert torch.equal(out0, F.pad(x.transpose(1, 2), (1, 3)).transpose(1, 2))
+    h = _rand((2, 9, 96), 22)
+    xg = ops.group_pad_pack(h.to(gpu), 2, 3).cpu()
+    ref = F.pad(h.view(2, 9, 2, 48).permute(0, 2, 1, 3), (0, 0, 3, 3))
+    assert torch.equal(xg, ref)
+    a = _rand((2, 8), 23)
+    assert torch.allclose(ops.add_rowbcast(x.to(gpu), a.to(gpu)).cpu(), x + a[:, None])

@@ -1,0 +1,29 @@
+"""End-to-end parity of the HIP wav2vec2 encoder against the CPU oracle (same seeded weights/audio)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,N,frame_num", [(2, 32000, None), (1, 64000, 100)])
+def test_wav2vec2_parity(gpu, B, N, frame_num):
+    from avi_talking_amd.weights import make_wav2vec2_weights
+    from avi_talking_amd.host.wav2vec import Wav2Vec2Model
+    from avi_talking_amd import ops
+    from oracle import wav2vec2 as O
+    w = make_wav2vec2_weights(0)
+    x = torch.randn(B, N, generator=torch.Generator().manual_seed(5))
+    ref = O.forward(w, x, frame_num=frame_num, return_intermediates=True)
+    model = Wav2Vec2Model(w, device=gpu, prec=ops.PREC_BF16X3)
+    out = model(x.to(gpu), "vocaset", frame_num=frame_num)
+    feats = out.extract_features.cpu()
+    e_conv = (feats - ref["conv"].transpose(1, 2)).abs().max().item()
+    e_out = (out.last_hidden_state.cpu() - ref["last_hidden_state"]).abs().max().item()
+    print(f"bf16x3: conv err {e_conv:.3e}, last_hidden_state err {e_out:.3e}")
+    assert out.last_hidden_state.shape == ref["last_hidden_state"].shape
+    assert e_conv < 1e-4
+    assert e_out < 1e-3          # north_star tolerance (fp32-grade path)
+    fast = Wav2Vec2Model(w, device=gpu, prec=ops.PREC_BF16)(x.to(gpu), "vocaset", frame_num=frame_num)
+    e_fast = (fast.last_hidden_state.cpu() - ref["last_hidden_state"]).abs().max().item()
+    print(f"bf16  : last_hidden_state err {e_fast:.3e}")
+    assert e_fast < 0.15         # single-pass bf16: ~4e-3 relative per GEMM through 20 layers
