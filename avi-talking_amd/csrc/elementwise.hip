@@ -206,14 +206,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // torch upsample_linear1d: scale = (Tin-1)/(Tout-1), src = scale*t, i0 = (int)src, l1 = src - i0.
 template <int MAXV>
 __global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict__ in, int B, int Tin, int C, int Tout,
-                                                         const float* __restrict__ gamma,
+                                                         const float scale, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          float* __restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B * Tout) return;
     const int b = row / Tout, t = row - b * Tout;
-    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
-    const float src = scale * (float)t;
+    // `scale` = (Tin-1)/(Tout-1) is divided on the host (IEEE).  The empty asm pins the rounded product:
+    // hipcc otherwise contracts scale*t - i0 into one v_fma_f32 (even through __fmul_rn/__fsub_rn), which
+    // moves the lerp weight by ~1e-5 away from torch's CPU upsample_linear1d.
+    float src = scale * (float)t;
+    asm volatile("" : "+v"(src));
     int i0 = (int)src;
     if (i0 > Tin - 1) i0 = Tin - 1;
     const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
@@ -366,8 +369,9 @@ extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int 
     if (!in || !out || B <= 0 || Tin <= 0 || Tout <= 0 || (C & 3) || C > 1024) return AVI_EINVAL;
     if ((gamma == nullptr) != (beta == nullptr)) return AVI_EINVAL;
     const int rows = B * Tout;
+    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
     hipLaunchKernelGGL(interp_ln_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
-                       B, Tin, C, Tout, gamma, beta, eps, out);
+                       B, Tin, C, Tout, scale, gamma, beta, eps, out);
     return avi_launch_status();
 }
 
