@@ -77,29 +77,32 @@ def linear(x, pw, out=None, act=ACT_NONE, residual=None, prec=PREC_BF16X3, scale
 
 
 def conv1d_cl(x, pw, ksize, stride, out=None, act=ACT_NONE, prec=PREC_BF16X3, scale=None, shift=None,
-              out_rows=None, out_row_stride=None, out_offset=0):
+              out_rows=None, out_row_stride=None, out_offset=0, in_row_offset=0):
     """Channels-last Conv1d without padding as an overlapping-row GEMM.
 
     x [B][Tin][Cin]; weight packed as [Cout][k*Cin] (tap-major); out [B][Tout][Cout] with
     Tout = (Tin-k)//stride+1.  ``out_rows``/``out_row_stride``/``out_offset`` let the caller
-    interleave rows into a larger buffer (ConvTranspose1d phases).
+    interleave rows into a larger buffer and ``in_row_offset`` skips leading input rows
+    (the two phases of a stride-2 ConvTranspose1d).
     """
     x = _f32c(x, "x")
     B, Tin, Cin = x.shape
     if pw.K != ksize * Cin:
         raise ValueError(f"conv1d_cl: weight K={pw.K} != k*Cin={ksize * Cin}")
-    Tout = (Tin - ksize) // stride + 1
+    Tout = (Tin - in_row_offset - ksize) // stride + 1
     if Tout <= 0:
         raise ValueError("conv1d_cl: input shorter than the kernel")
     if out is None:
         out = torch.empty((B, Tout, pw.N), dtype=torch.float32, device=x.device)
     _f32c(out, "out")
     rows = Tout if out_rows is None else out_rows
+    if rows > Tout:
+        raise ValueError("conv1d_cl: more output rows requested than the input provides")
     ldc = pw.N if out_row_stride is None else out_row_stride
     per_b = out.numel() // B
     if out_offset + (rows - 1) * ldc + pw.N > per_b:
         raise ValueError("conv1d_cl: output rows exceed the out buffer")
-    gemm_raw(A=x.data_ptr(), lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+    gemm_raw(A=x.data_ptr() + 4 * in_row_offset * Cin, lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
              C_=out.data_ptr() + 4 * out_offset, ldc=ldc, M=rows, N=pw.N, K=pw.K, bias=L.ptr(pw.bias),
              scale=L.ptr(scale), shift=L.ptr(shift), act=act, prec=prec, batch=B, z_inner=1,
              sA=(Tin * Cin, 0), sC=(per_b, 0))

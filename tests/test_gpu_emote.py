@@ -1,0 +1,66 @@
+"""GPU parity: EMOTE head + FLINT decoder (row D) and the full audio->coefficients path vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, T, seed=31):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, T, 768, generator=g), torch.randn(B, 1, 128, generator=g) * 0.5
+
+
+@pytest.mark.parametrize("B,T", [(2, 250), (1, 61), (3, 8)])
+def test_emote_head_parity(gpu, B, T):
+    from avi_talking_amd import ops
+    from avi_talking_amd.weights import make_emote_weights
+    from avi_talking_amd.host.talking_head import EmoteHead
+    from oracle import emote as OE
+    w = make_emote_weights(1)
+    feat, style = _inputs(B, T)
+    ref = OE.forward(w, feat, style, return_intermediates=True)
+    head = EmoteHead(w, device=gpu, prec=ops.PREC_BF16X3)
+    out = head(feat.to(gpu), style.to(gpu))
+    e_lat = (out["latent"].cpu() - ref["latent"]).abs().max().item()
+    e_exp = (out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item()
+    e_jaw = (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item()
+    print(f"B={B} T={T}: latent {e_lat:.2e} exp {e_exp:.2e} jaw {e_jaw:.2e} (scale {ref['predicted_exp'].std():.2f})")
+    assert out["predicted_exp"].shape == (B, T, 50) and out["predicted_jaw"].shape == (B, T, 3)
+    assert max(e_exp, e_jaw) < 1e-3          # north_star tolerance on predicted coefficients
+    assert max(e_exp, e_jaw) < 2e-4          # what the bf16x3 path actually delivers
+
+
+def test_style_condition_and_wrapper(gpu):
+    """TalkingHeadWrapper protocol: only_style_emb returns (B,T,128); external style is used as given."""
+    from avi_talking_amd.weights import make_emote_weights, make_wav2vec2_weights
+    from avi_talking_amd.host.talking_head import TalkingHeadWrapper
+    from oracle import emote as OE, wav2vec2 as OW
+    wa, wh = make_wav2vec2_weights(0), make_emote_weights(1)
+    B, T = 2, 25
+    g = torch.Generator().manual_seed(41)
+    raw = (torch.randn(B, T, 640, generator=g) * 3000).to(torch.int16)
+    expr = torch.nn.functional.one_hot(torch.tensor([3, 5]), 8)[:, None].expand(B, T, 8)
+    inten = torch.nn.functional.one_hot(torch.tensor([2, 0]), 3)[:, None].expand(B, T, 3)
+    ident = torch.nn.functional.one_hot(torch.tensor([7, 30]), 32)[:, None].expand(B, T, 32)
+    shape = torch.randn(B, 300, generator=g)
+    sample = {"raw_audio": raw, "samplerate": [16000] * B, "gt_shape": shape,
+              "gt_expression_label_condition": expr, "gt_expression_intensity_condition": inten,
+              "gt_expression_identity_condition": ident}
+    th = TalkingHeadWrapper(wa, wh, device=gpu)
+    style = th(dict(sample), only_style_emb=True)
+    ref_style = OE.style_condition(wh, expr, inten, ident, shape)
+    assert style.shape == (B, T, 128)
+    assert (style.cpu() - ref_style).abs().max().item() < 1e-4
+    ext = torch.randn(B, 1, 128, generator=g) * 0.5
+    out = th(dict(sample), style_emb=ext.to(gpu), is_external_style_emb=True)
+    x = OW.normalize_audio(raw.reshape(B, -1), joint=True)
+    feat = OW.forward(wa, x, frame_num=T)
+    ref = OE.forward(wh, feat, ext)
+    e = max((out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
+            (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
+    print(f"full path audio->coeffs err {e:.2e}")
+    assert e < 1e-3
+    own = th(dict(sample))                       # style from the sample's own conditions
+    ref_own = OE.forward(wh, feat, ref_style)
+    assert (own["predicted_exp"].cpu() - ref_own["predicted_exp"]).abs().max().item() < 1e-3

@@ -1,0 +1,83 @@
+"""CPU: the oracle restatements against golden vectors produced by importing the reference
+(tests/golden/make_golden.py).  These pin the oracle; the GPU tests then compare HIP vs oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from avi_talking_amd import weights as W
+from oracle import emote as OE
+from oracle import faceformer as OF
+from oracle import prior as OP
+from oracle import wav2vec2 as OW
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope="module")
+def w2v_weights():
+    return W.make_wav2vec2_weights(0)
+
+
+@pytest.mark.parametrize("tag", ["fixture", "randn", "randn_fn40"])
+def test_wav2vec2_oracle_matches_reference(w2v_weights, tag):
+    g = _load(f"wav2vec2_{tag}.npz")
+    if tag == "fixture":
+        pcm = _load("fixture_wav_ch0.npz")["pcm"]
+        assert np.array_equal(pcm[:64], g["pcm_head"])
+        x = OW.normalize_audio(torch.from_numpy(pcm.astype(np.float32))[None])
+    else:
+        x = torch.randn(1, 32000, generator=torch.Generator().manual_seed(5))
+    assert x.shape[1] == int(g["n_samples"])
+    fn = int(g["frame_num"])
+    out = OW.forward(w2v_weights, x, frame_num=None if fn < 0 else fn, return_intermediates=True)
+    assert list(out["conv"].shape) == list(g["conv_shape"])
+    assert list(out["last_hidden_state"].shape) == list(g["out_shape"])
+    assert np.abs(out["conv"][0, ::16, ::9].numpy() - g["conv_slice"]).max() < 1e-5
+    assert np.abs(out["last_hidden_state"][0, ::3, ::8].numpy() - g["out_slice"]).max() < 5e-5
+
+
+def test_masks_match_reference():
+    g = _load("masks.npz")
+    m30 = OE.faceformer_biased_mask(4, 600, 30)
+    assert np.array_equal(m30[:, :96, :96].numpy(), g["biased_p30_block"])
+    assert np.array_equal(m30[:, ::13, ::7].numpy(), g["biased_p30_strided"])
+    assert np.array_equal(OE.faceformer_biased_mask(4, 64, 25).numpy(), g["biased_p25_block"])
+    assert np.allclose(OE.alibi_future_mask(8, 96).numpy(), g["alibi_future_8_96"], atol=0, rtol=0)
+    assert np.array_equal(OF.enc_dec_mask(7, 9).numpy(), g["enc_dec_7_9"])
+    assert np.array_equal(OF.ppe_table(64, 30)[0, :100].numpy(), g["ppe_64_p30"])
+
+
+def test_brain_network_matches_reference():
+    g = _load("brain.npz")
+    w = W.make_prior_weights(3)
+    a, b = OP.brain_network(w, torch.from_numpy(g["x"]))
+    assert np.abs(a.numpy() - g["out"]).max() < 2e-5
+    assert np.abs(b.numpy() - g["proj"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("D", [64, 1024])
+def test_faceformer_predict_matches_reference(D):
+    g = _load(f"faceformer_D{D}.npz")
+    w = W.make_faceformer_weights(2, feature_dim=D)
+    mean = torch.from_numpy(_load("coeff_mean.npy"))[None, None]
+    std = torch.from_numpy(_load("coeff_std.npy"))[None, None]
+    hs = torch.from_numpy(g["hidden_states"])
+    ref = g["predict"]
+    out = OF.predict_as_written(w, hs, 30, mean, std)
+    assert out.shape == ref.shape
+    assert np.abs(out.numpy() - ref).max() < 2e-5
+    cached = OF.predict_cached(w, hs, 30, mean, std)
+    assert np.abs(cached.numpy() - ref).max() < 5e-5
+
+
+def test_coeff_stats_fixture():
+    """misc/coeff_{mean,std}.npy: float32 [53]; jaw std is tiny."""
+    m, s = _load("coeff_mean.npy"), _load("coeff_std.npy")
+    assert m.shape == (53,) and s.shape == (53,) and m.dtype == np.float32
+    assert np.allclose(s[50:53], [0.04804965, 0.0071304, 0.02132538])
