@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 
 // ------------------------------------------------------------------ LayerNorm helpers (one wave per row)
 template <int MAXV>  // MAXV float4 per lane held in registers: C <= 256*MAXV
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int rows, int C,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int rows, int C,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ out) {
+                                                         const float* __restrict__ beta, float eps, int act,
+                                                         const float* residual, float* out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* x = in + (long long)row * C;
@@ -193,10 +193,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (gamma) g = reinterpret_cast<const float4*>(gamma)[idx];
             if (beta) bb = reinterpret_cast<const float4*>(beta)[idx];
             float4 r;
-            r.x = (v[i].x - mean) * rstd * g.x + bb.x;
-            r.y = (v[i].y - mean) * rstd * g.y + bb.y;
-            r.z = (v[i].z - mean) * rstd * g.z + bb.z;
-            r.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            r.x = avi_act((v[i].x - mean) * rstd * g.x + bb.x, act);
+            r.y = avi_act((v[i].y - mean) * rstd * g.y + bb.y, act);
+            r.z = avi_act((v[i].z - mean) * rstd * g.z + bb.z, act);
+            r.w = avi_act((v[i].w - mean) * rstd * g.w + bb.w, act);
+            if (residual) {
+                const float4 rr = reinterpret_cast<const float4*>(residual + (long long)row * C)[idx];
+                r.x += rr.x; r.y += rr.y; r.z += rr.z; r.w += rr.w;
+            }
             reinterpret_cast<float4*>(o)[idx] = r;
         }
     }
@@ -375,16 +379,21 @@ extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int 
     return avi_launch_status();
 }
 
-extern "C" int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
-                             float* out, void* stream) {
+extern "C" int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                                 int act, const float* residual, float* out, void* stream) {
     if (!in || !out || rows <= 0 || C <= 0 || (C & 3) || C > 4096) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, out);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, residual, out);
     else
-        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, out);
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, residual, out);
     return avi_launch_status();
+}
+
+extern "C" int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                             float* out, void* stream) {
+    return avi_layernorm_act(in, rows, C, gamma, beta, eps, AVI_ACT_NONE, nullptr, out, stream);
 }
 
 extern "C" int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, float* xg, void* stream) {

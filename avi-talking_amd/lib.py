@@ -32,6 +32,21 @@ class AviGemm(C.Structure):
     ]
 
 
+PRIOR_MAX_DEPTH = 8
+
+
+class AviPriorLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("norm_g", "wqkv", "null_kv", "wout", "out_g", "ff_g", "w1", "w2")]
+
+
+class AviPriorWeights(C.Structure):
+    _fields_ = ([("depth", _i), ("timesteps", _i)] +
+                [(n, _vp) for n in ("time_table", "t_w0", "t_b0", "t_w1", "t_b1", "t_w2", "t_b2", "learned_query",
+                                    "null_brain", "null_image", "rel_bias", "rot_cos", "rot_sin")] +
+                [("layer", AviPriorLayer * PRIOR_MAX_DEPTH)] +
+                [(n, _vp) for n in ("final_g", "wproj", "coef1", "coef2", "logvar")])
+
+
 # name -> argtypes; every function returns int status.  Kept in one table so the CPU-side test can
 # check that the library exports every symbol the header declares.
 SIGNATURES = {
@@ -41,10 +56,13 @@ SIGNATURES = {
     "avi_conv0_gn_gelu": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "avi_layernorm_act": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+    "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp],
 }
 
 _lib = None

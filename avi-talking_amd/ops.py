@@ -147,14 +147,17 @@ def interp_layernorm(x, Tout, gamma=None, beta=None, eps=1e-5):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None):
+def layernorm(x, gamma, beta, eps=1e-5, out=None, act=ACT_NONE, residual=None):
+    """out = act(LN(x)) + residual."""
     x = _f32c(x, "x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     if out is None:
         out = torch.empty_like(x)
-    L.check(L.load().avi_layernorm(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps, out.data_ptr(),
-                                   L.stream_ptr()), "avi_layernorm")
+    if residual is not None and _f32c(residual, "residual").numel() != x.numel():
+        raise ValueError("layernorm: bad residual shape")
+    L.check(L.load().avi_layernorm_act(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps, act, L.ptr(residual),
+                                       out.data_ptr(), L.stream_ptr()), "avi_layernorm_act")
     return out
 
 

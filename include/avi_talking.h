@@ -94,6 +94,10 @@ int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const
 /* row LayerNorm: out[r] = LN(in[r]) * gamma + beta, rows x C.  in == out allowed. */
 int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
                   float* out, void* stream);
+/* out[r] = act(LN(in[r])) + residual[r]  (BrainNetwork blocks: Linear -> LayerNorm -> GELU -> +residual,
+ * models/diffusion_prior.py:64-76,106-110).  residual may be NULL; in == out allowed. */
+int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                      int act, const float* residual, float* out, void* stream);
 
 /* pos-conv input packing: h [B][T][G*Cg] -> xg [B][G][T+2*pad][Cg], zero padded (pad = 64, Cg = 48). */
 int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, float* xg, void* stream);
@@ -118,6 +122,50 @@ int avi_add_rowbcast(const float* in, const float* add, int B, int T, int C, flo
 int avi_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk,
                   int D, int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes,
                   int period, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diffusion prior.  Replaces VersatileDiffusionPriorNetwork.forward (models/diffusion_prior.py:223-313),
+ * FlaggedCausalTransformer.forward (:154-166) with the dalle2 Attention/FeedForward/LayerNorm blocks,
+ * and InstructDiffusionPrior.p_sample / p_sample_loop_ddpm (:329-367) + dalle2 q_posterior.
+ * All pointers are fp32 device arrays.  Linear weights are stored TRANSPOSED, [K][N] (in x out).
+ * ---------------------------------------------------------------------------------------- */
+#define AVI_PRIOR_MAX_DEPTH 8
+typedef struct AviPriorLayer {
+    const float* norm_g;   /* [128]       layers.{l}.0.norm.g */
+    const float* wqkv;     /* [128][640]  cat(to_q.weight, to_kv.weight)^T : q 512 | k 64 | v 64 */
+    const float* null_kv;  /* [2][64]     layers.{l}.0.null_kv */
+    const float* wout;     /* [512][128]  to_out.0.weight^T */
+    const float* out_g;    /* [128]       to_out.1.g */
+    const float* ff_g;     /* [128]       layers.{l}.1.0.g */
+    const float* w1;       /* [128][1024] layers.{l}.1.1.weight^T (value 512 | gate 512) */
+    const float* w2;       /* [512][128]  layers.{l}.1.5.weight^T */
+} AviPriorLayer;
+typedef struct AviPriorWeights {
+    int depth, timesteps;
+    const float* time_table;                 /* [timesteps][128] SinusoidalPosEmb(t) */
+    const float *t_w0, *t_b0;                /* [128][256], [256]   to_time_embeds MLP */
+    const float *t_w1, *t_b1;                /* [256][256], [256] */
+    const float *t_w2, *t_b2;                /* [256][128], [128] */
+    const float* learned_query;              /* [128] (learned_query_mode "pos_emb") */
+    const float* null_brain;                 /* [128] null_brain_embeds */
+    const float* null_image;                 /* [128] null_image_embed */
+    const float* rel_bias;                   /* [8][3][4] RelPosBias(n=3, n+1=4) gathered from the (32,8) table */
+    const float *rot_cos, *rot_sin;          /* [3][32] rotary cos/sin for positions 0..2 */
+    AviPriorLayer layer[AVI_PRIOR_MAX_DEPTH];
+    const float* final_g;                    /* [128] causal_transformer.norm.g (stable LayerNorm) */
+    const float* wproj;                      /* [128][128] project_out.weight^T */
+    const float *coef1, *coef2, *logvar;     /* [timesteps] posterior_mean_coef1/2, posterior_log_variance_clipped */
+} AviPriorWeights;
+
+/* One denoiser evaluation per sample (training forward / unit of the sampler):
+ * x_t [B][128], t [B] int32, text_embed [B][128], keep masks [B] bytes or NULL (= keep) -> pred [B][128]. */
+int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, const float* text_embed,
+                      const unsigned char* brain_keep, const unsigned char* image_keep, int B, float* pred,
+                      void* stream);
+/* Whole DDPM loop in ONE launch (one workgroup per sample): noise [timesteps+1][B][128], noise[0] = x_T,
+ * noise[1+k] = z of the k-th step; out [B][128] = x_0 * inv_scale (inv_scale = 1/sqrt(128)). */
+int avi_prior_sample(const AviPriorWeights* w, const float* text_embed, const float* noise, int B,
+                     float inv_scale, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,72 @@
+"""GPU parity: BrainNetwork aligner, prior denoiser step and the 100-step DDPM loop vs the oracle.
+The dalle2 pieces of the oracle are restated by specification (parity unpinned, see oracle/prior.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pw():
+    from avi_talking_amd.weights import make_prior_weights
+    return make_prior_weights(3)
+
+
+def test_brain_network_parity(gpu, pw):
+    from avi_talking_amd.host.diffusion_prior import BrainNetwork
+    from oracle import prior as OP
+    g = np.load(os.path.join(G, "brain.npz"))
+    net = BrainNetwork(pw, device=gpu)
+    a, b = net(torch.from_numpy(g["x"]).to(gpu))
+    # against the golden produced by the REFERENCE class itself
+    assert np.abs(a.cpu().numpy() - g["out"]).max() < 2e-4
+    assert np.abs(b.cpu().numpy() - g["proj"]).max() < 2e-4
+    x = torch.randn(64, 768, generator=torch.Generator().manual_seed(12))
+    ra, rb = OP.brain_network(pw, x)
+    a, b = net(x.to(gpu))
+    print("brain err", (a.cpu() - ra).abs().max().item(), (b.cpu() - rb).abs().max().item())
+    assert (a.cpu() - ra).abs().max().item() < 2e-4 and (b.cpu() - rb).abs().max().item() < 2e-4
+
+
+def test_prior_step_parity(gpu, pw):
+    from avi_talking_amd.host.diffusion_prior import VersatileDiffusionPriorNetwork
+    from oracle import prior as OP
+    B = 7
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 1, 128, generator=g) * 3
+    te = torch.randn(B, 1, 128, generator=g)
+    t = torch.tensor([0, 1, 17, 50, 98, 99, 63])
+    bk = torch.tensor([1, 1, 0, 1, 0, 1, 1], dtype=torch.bool)
+    ik = torch.tensor([1, 0, 1, 1, 0, 1, 1], dtype=torch.bool)
+    net = VersatileDiffusionPriorNetwork(pw, device=gpu)
+    ref = OP.prior_net(pw, x, t, te)
+    out = net(x.to(gpu), t.to(gpu), text_embed=te.to(gpu)).cpu()
+    e1 = (out - ref).abs().max().item()
+    ref2 = OP.prior_net(pw, x, t, te, bk, ik)
+    out2 = net(x.to(gpu), t.to(gpu), text_embed=te.to(gpu), brain_keep_mask=bk, image_keep_mask=ik).cpu()
+    e2 = (out2 - ref2).abs().max().item()
+    print(f"prior step err {e1:.2e} (masked {e2:.2e}), scale {ref.std():.2f}")
+    assert e1 < 1e-4 and e2 < 1e-4
+
+
+@pytest.mark.parametrize("B", [3, 32])
+def test_ddpm_sampling_parity(gpu, pw, B):
+    from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior
+    from oracle import prior as OP
+    g = torch.Generator().manual_seed(14)
+    te = torch.randn(B, 1, 128, generator=g)
+    noise = torch.randn(101, B, 1, 128, generator=torch.Generator().manual_seed(0))
+    prior = InstructDiffusionPrior.from_state_dict(pw, device=gpu)
+    out = prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": te.to(gpu)}, cond_scale=1.0, timesteps=100,
+                              noise=noise.to(gpu)).cpu()
+    nb = min(B, 4)           # the CPU oracle loop is slow; samples are independent
+    ref = OP.p_sample_loop(pw, te[:nb], noise[:, :nb])
+    err = (out[:nb] - ref).abs().max().item()
+    print(f"DDPM 100-step err {err:.2e}, scale {ref.std():.3f}")
+    assert out.shape == (B, 1, 128)
+    assert torch.isfinite(out).all()
+    assert err < 1e-3
