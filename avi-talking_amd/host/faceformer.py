@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference ``models/faceformer.py`` ``Faceformer`` (decoder side).
+
+``predict(audio, head_img, eye_img, emotion_img, text=None)`` keeps the reference signature
+(models/faceformer.py:670) and returns un-normalised coefficients ``(B, T, 53)``.  The FAN image
+encoder that turns the three image arguments into per-frame embeddings
+(third_party/pd_fgc_inference, models/faceformer.py:677-697) is out of scope; callers
+that have those embeddings pass them as ``cond_embeds=(eye (B,T,6), emo (B,T,30), head (B,T,6))`` and the
+``v_merge2hidden`` Linear (:185,707-708) is applied; without them the memory is
+``audio_feature_map(wav2vec2(audio))`` as in upstream FaceFormer.
+
+Unlike the reference (batch forced to 1 by its 3-D mask, prefix re-decoded every step) the HIP path
+decodes B utterances at once with a KV cache, all T steps in one launch.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from .. import lib as L
+from .. import ops
+from .wav2vec import Wav2Vec2Model
+
+NHEAD = 4
+
+
+def alibi_slopes(n):
+    """models/faceformer.py:52-62."""
+    def pow2(n):
+        start = 2 ** (-2 ** -(math.log2(n) - 3))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n).is_integer():
+        return pow2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return pow2(c) + alibi_slopes(2 * c)[0::2][:n - c]
+
+
+def ppe_period(d_model, period):
+    """One period of PeriodicPositionalEncoding (models/faceformer.py:87-99)."""
+    pe = torch.zeros(period, d_model)
+    position = torch.arange(0, period, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def _pad_k(w2d, mult=64):
+    N, K = w2d.shape
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return w2d.contiguous()
+    out = torch.zeros((N, Kp), dtype=w2d.dtype, device=w2d.device)
+    out[:, :K] = w2d
+    return out
+
+
+class Faceformer:
+    def __init__(self, state_dict, audio_state_dict=None, period=30, device="cuda", prec=ops.PREC_BF16X3,
+                 coeff_mean=None, coeff_std=None, max_seq_len=600):
+        self.device = torch.device(device)
+        self.prec = prec
+        self.period = period
+        self.max_seq_len = max_seq_len          # reference mask / PPE tables stop at 600 frames (:88,147)
+        w = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}
+        self.D = w["audio_feature_map.weight"].shape[0]
+        self.V = w["vertice_map_r.weight"].shape[0]
+        self.audio_encoder = (Wav2Vec2Model(audio_state_dict, device=device, prec=prec)
+                              if audio_state_dict is not None else None)
+        dv = lambda t: t.to(self.device).contiguous()
+        self.audio_feature_map = ops.PackedWeight(dv(w["audio_feature_map.weight"]), dv(w["audio_feature_map.bias"]))
+        self.v_merge2hidden = None
+        if "v_merge2hidden.weight" in w:
+            self.v_merge2hidden = ops.PackedWeight(_pad_k(dv(w["v_merge2hidden.weight"])),
+                                                   dv(w["v_merge2hidden.bias"]))
+            self.merge_in = w["v_merge2hidden.weight"].shape[1]
+        p = "transformer_decoder.layers.0."
+        D = self.D
+        Wc, bc = w[p + "multihead_attn.in_proj_weight"], w[p + "multihead_attn.in_proj_bias"]
+        self.cross_v = ops.PackedWeight(dv(Wc[2 * D:]), dv(bc[2 * D:]))
+        self.cross_o = ops.PackedWeight(dv(w[p + "multihead_attn.out_proj.weight"]),
+                                        dv(w[p + "multihead_attn.out_proj.bias"]))
+        self._keep = []
+
+        def dev(t):
+            t = dv(t)
+            self._keep.append(t)
+            return t.data_ptr()
+
+        cw = L.AviFaceformerWeights()
+        cw.D, cw.V, cw.period = D, self.V, period
+        cw.wqkv, cw.bqkv = dev(w[p + "self_attn.in_proj_weight"].t()), dev(w[p + "self_attn.in_proj_bias"])
+        cw.wo, cw.bo = dev(w[p + "self_attn.out_proj.weight"].t()), dev(w[p + "self_attn.out_proj.bias"])
+        for i in (1, 2, 3):
+            setattr(cw, f"n{i}g", dev(w[p + f"norm{i}.weight"]))
+            setattr(cw, f"n{i}b", dev(w[p + f"norm{i}.bias"]))
+        cw.w1, cw.b1 = dev(w[p + "linear1.weight"].t()), dev(w[p + "linear1.bias"])
+        cw.w2, cw.b2 = dev(w[p + "linear2.weight"].t()), dev(w[p + "linear2.bias"])
+        cw.wr, cw.br = dev(w["vertice_map_r.weight"].t()), dev(w["vertice_map_r.bias"])
+        cw.wm, cw.bm = dev(w["vertice_map.weight"].t()), dev(w["vertice_map.bias"])
+        cw.pe = dev(ppe_period(D, period))
+        cw.slopes = dev(torch.tensor(alibi_slopes(NHEAD), dtype=torch.float32))
+        cw.obj_embedding = dev(w["obj_embedding"].reshape(-1))
+        if coeff_mean is not None:
+            cw.coeff_mean = dev(torch.as_tensor(coeff_mean, dtype=torch.float32).reshape(-1)[: self.V])
+            cw.coeff_std = dev(torch.as_tensor(coeff_std, dtype=torch.float32).reshape(-1)[: self.V])
+        self.cw = cw
+
+    def decode(self, hidden_states):
+        """The autoregressive loop of ``predict`` (:710-729) for memory ``hidden_states`` (B,T,D)."""
+        hs = hidden_states.to(self.device, torch.float32).contiguous()
+        B, T, D = hs.shape
+        if D != self.D:
+            raise ValueError(f"hidden_states has D={D}, decoder has D={self.D}")
+        if T > self.max_seq_len:
+            raise ValueError(f"T={T} exceeds the reference's mask/PPE length {self.max_seq_len}")
+        cross = ops.linear(ops.linear(hs, self.cross_v, prec=self.prec), self.cross_o, prec=self.prec)
+        kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
+        L.check(L.load().avi_faceformer_decode(C.byref(self.cw), cross.data_ptr(), B, T, kv.data_ptr(),
+                                               out.data_ptr(), L.stream_ptr()), "avi_faceformer_decode")
+        return out
+
+    @torch.no_grad()
+    def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None):
+        if self.audio_encoder is None:
+            raise RuntimeError("Faceformer was built without audio encoder weights")
+        feats = self.audio_encoder(audio.to(self.device), "vocaset").last_hidden_state     # :673
+        hs = ops.linear(feats, self.audio_feature_map, prec=self.prec)                     # :674
+        if cond_embeds is not None:
+            if self.v_merge2hidden is None:
+                raise RuntimeError("cond_embeds given but the state_dict has no v_merge2hidden")
+            eye, emo, head = [t.to(self.device, torch.float32) for t in cond_embeds]
+            B, T, _ = hs.shape
+            cat = torch.zeros((B, T, self.v_merge2hidden.K), dtype=torch.float32, device=self.device)
+            o = 0
+            for part in (eye, emo, hs, head):                                              # :707
+                cat[..., o:o + part.shape[-1]] = part
+                o += part.shape[-1]
+            if o != self.merge_in:
+                raise ValueError("cond_embeds do not match v_merge2hidden's input width")
+            hs = ops.linear(cat, self.v_merge2hidden, prec=self.prec)                      # :708
+        return self.decode(hs)

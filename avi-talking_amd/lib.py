@@ -47,6 +47,13 @@ class AviPriorWeights(C.Structure):
                 [(n, _vp) for n in ("final_g", "wproj", "coef1", "coef2", "logvar")])
 
 
+class AviFaceformerWeights(C.Structure):
+    _fields_ = ([("D", _i), ("V", _i), ("period", _i)] +
+                [(n, _vp) for n in ("wqkv", "bqkv", "wo", "bo", "n1g", "n1b", "n2g", "n2b", "n3g", "n3b", "w1", "b1",
+                                    "w2", "b2", "wr", "br", "wm", "bm", "pe", "slopes", "obj_embedding",
+                                    "coeff_mean", "coeff_std")])
+
+
 # name -> argtypes; every function returns int status.  Kept in one table so the CPU-side test can
 # check that the library exports every symbol the header declares.
 SIGNATURES = {
@@ -63,6 +70,7 @@ SIGNATURES = {
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp],
+    "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -167,6 +167,32 @@ int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, 
 int avi_prior_sample(const AviPriorWeights* w, const float* text_embed, const float* noise, int B,
                      float inv_scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FaceFormer-style autoregressive decoder.  Replaces the loop of Faceformer.predict
+ * (models/faceformer.py:710-729; teacher-free branch of forward_switch_frame :392-409) over
+ * init_biased_mask (:51-72), enc_dec_mask (:75-83), PeriodicPositionalEncoding (:87-102) and the
+ * nn.TransformerDecoderLayer(d, 4 heads, ff 2d, ReLU, post-LN) built at :148-149.
+ * All pointers fp32 device arrays; Linear weights TRANSPOSED to [K][N].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct AviFaceformerWeights {
+    int D, V, period;                 /* feature_dim (D/4 a power of two >= 4), vertice_dim (<= 64), PPE/ALiBi period */
+    const float *wqkv, *bqkv;         /* [D][3D], [3D]  self_attn.in_proj */
+    const float *wo, *bo;             /* [D][D], [D]    self_attn.out_proj */
+    const float *n1g, *n1b, *n2g, *n2b, *n3g, *n3b;   /* norm1..3 */
+    const float *w1, *b1;             /* [D][2D], [2D]  linear1 */
+    const float *w2, *b2;             /* [2D][D], [D]   linear2 */
+    const float *wr, *br;             /* [D][V], [V]    vertice_map_r */
+    const float *wm, *bm;             /* [V][D], [D]    vertice_map */
+    const float* pe;                  /* [period][D]    one period of the PPE table */
+    const float* slopes;              /* [4]            ALiBi head slopes */
+    const float* obj_embedding;       /* [D]            start token */
+    const float *coeff_mean, *coeff_std;  /* [V] or both NULL: out = out*std + mean (misc/coeff_{mean,std}.npy) */
+} AviFaceformerWeights;
+/* cross [B][T][D] = multihead_attn.out_proj(v_proj(memory)) (the diagonal memory mask makes cross-attention at
+ * step i read memory row i only); kv_scratch >= B*T*2*D floats; out [B][T][V]. One launch for all T steps. */
+int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
+                          float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,60 @@
+"""GPU parity: FaceFormer autoregressive decoder (row E) vs the oracle and vs the golden produced by running
+the reference's ``Faceformer.predict`` unmodified."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("D", [64, 1024])
+def test_decode_matches_reference_golden(gpu, D):
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    g = np.load(os.path.join(G, f"faceformer_D{D}.npz"))
+    w = make_faceformer_weights(2, feature_dim=D)
+    mean, std = np.load(os.path.join(G, "coeff_mean.npy")), np.load(os.path.join(G, "coeff_std.npy"))
+    ff = Faceformer(w, period=30, device=gpu, coeff_mean=mean, coeff_std=std)
+    out = ff.decode(torch.from_numpy(g["hidden_states"]).to(gpu)).cpu().numpy()
+    err = np.abs(out - g["predict"]).max()
+    # also in normalised space: jaw std is 0.007-0.05, so normalised errors are 20-140x larger (row G)
+    err_n = np.abs((out - g["predict"]) / std).max()
+    print(f"D={D}: max-abs coeff err vs reference predict {err:.2e} (normalised {err_n:.2e})")
+    assert out.shape == g["predict"].shape
+    assert err < 1e-3 and err_n < 1e-3
+
+
+@pytest.mark.parametrize("B,T,D,period", [(3, 100, 64, 25), (2, 40, 128, 30), (1, 300, 64, 30)])
+def test_decode_batched_vs_oracle(gpu, B, T, D, period):
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF
+    w = make_faceformer_weights(2, feature_dim=D)
+    hs = torch.randn(B, T, D, generator=torch.Generator().manual_seed(51))
+    ref = OF.predict_cached(w, hs, period)
+    out = Faceformer(w, period=period, device=gpu).decode(hs.to(gpu)).cpu()
+    err = (out - ref).abs().max().item()
+    print(f"B={B} T={T} D={D}: err {err:.2e} scale {ref.std():.2f}")
+    assert err < 1e-3
+
+
+def test_predict_end_to_end(gpu):
+    """audio -> wav2vec2 -> audio_feature_map -> AR decode -> un-normalise, against the oracle chain."""
+    from avi_talking_amd.weights import make_faceformer_weights, make_wav2vec2_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF, wav2vec2 as OW
+    import torch.nn.functional as F
+    wa, w = make_wav2vec2_weights(0), make_faceformer_weights(2, feature_dim=64)
+    mean, std = np.load(os.path.join(G, "coeff_mean.npy")), np.load(os.path.join(G, "coeff_std.npy"))
+    audio = torch.randn(2, 24000, generator=torch.Generator().manual_seed(5))
+    ff = Faceformer(w, audio_state_dict=wa, period=30, device=gpu, coeff_mean=mean, coeff_std=std)
+    out = ff.predict(audio.to(gpu)).cpu()
+    feats = OW.forward(wa, audio)
+    hs = F.linear(feats, w["audio_feature_map.weight"], w["audio_feature_map.bias"])
+    ref = OF.predict_cached(w, hs, 30, torch.from_numpy(mean), torch.from_numpy(std))
+    err = (out - ref).abs().max().item()
+    print(f"predict end-to-end err {err:.2e}")
+    assert out.shape == ref.shape and err < 1e-3
