@@ -13,63 +13,64 @@
 namespace {
 
 constexpr int DIM = 128, NTOK = 3, HEADS = 8, DH = 64, INNER = HEADS * DH, FFI = 512, ROT = 32;
-constexpr int NT = 256;
+constexpr int NT = 1024;   // 16 waves: enough 16-B weight loads in flight to stream from L2/MALL at rate
 
 struct Smem {
     float tok[NTOK][DIM];      // residual stream
     float xn[NTOK][DIM];       // normed input / scratch
     float big[NTOK][2 * FFI];  // q|kv (640 used) or FF hidden (1024)
     float att[NTOK][INNER];    // attention output / swiglu output
-    float part[2][NTOK][DIM];  // split-K partials for N = 128 linears
+    float part[12288];         // split-K partials [KS][3][N] of the streamed linears (KS*N <= 4096)
     float kn[4][DH];           // [null, k0, k1, k2] normalised keys
     float vv[4][DH];           // [null, v0, v1, v2]
     float sim[HEADS][NTOK][4];
     float tmp[2 * DIM];
 };
 
-// out[m][n] = sum_k x[m][k] * Wt[k][n]  for n in [0, N); x in LDS with row stride xs, N >= 256.
-template <int K>
-__device__ __forceinline__ void linear_wide(const float* __restrict__ Wt, int N, const float* x, int xs, float* out,
-                                            int os) {
-    for (int n = threadIdx.x; n < N; n += NT) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < K; k += 4) {
-            const float4 x0 = *reinterpret_cast<const float4*>(x + k);
-            const float4 x1 = *reinterpret_cast<const float4*>(x + xs + k);
-            const float4 x2 = *reinterpret_cast<const float4*>(x + 2 * xs + k);
-            const float w0 = Wt[(long long)(k + 0) * N + n], w1 = Wt[(long long)(k + 1) * N + n];
-            const float w2 = Wt[(long long)(k + 2) * N + n], w3 = Wt[(long long)(k + 3) * N + n];
-            a0 = fmaf(x0.x, w0, a0); a0 = fmaf(x0.y, w1, a0); a0 = fmaf(x0.z, w2, a0); a0 = fmaf(x0.w, w3, a0);
-            a1 = fmaf(x1.x, w0, a1); a1 = fmaf(x1.y, w1, a1); a1 = fmaf(x1.z, w2, a1); a1 = fmaf(x1.w, w3, a1);
-            a2 = fmaf(x2.x, w0, a2); a2 = fmaf(x2.y, w1, a2); a2 = fmaf(x2.z, w2, a2); a2 = fmaf(x2.w, w3, a2);
+// out[m][n] = sum_k x[m][k] * Wt[k][n] (m < 3) with the weight matrix streamed ONCE as 16-B loads:
+// thread = (column quad cq, K slice ks); NV = N/4 quads, KS = NT/NV slices.  Each thread issues all of its
+// slice's loads back to back (no dependence between them), so a workgroup keeps hundreds of KB in flight.
+// Partials go to s.part[ks][m][n]; reduce3() sums them.
+template <int K, int N>
+__device__ __forceinline__ void linear3_partial(const float* __restrict__ Wt, const float* x, int xs, Smem& s) {
+    constexpr int NV = N / 4;
+    constexpr int KS = NT / NV;                 // 4 (N=1024), 6 (N=640), 32 (N=128)
+    constexpr int KC = (K + KS - 1) / KS;       // k per slice
+    static_assert(KS * N * 3 <= 12288, "partial buffer too small");
+    const int cq = threadIdx.x % NV, ks = threadIdx.x / NV;
+    if (ks >= KS) return;
+    const int k0 = ks * KC;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    const float4* wp = reinterpret_cast<const float4*>(Wt) + cq;
+#pragma unroll 4   // 4 x 16 B per lane in flight per batch (x 16 waves = 64 KB per CU); deeper unrolls spill at 128 VGPRs
+    for (int kk = 0; kk < KC; ++kk) {
+        const int k = k0 + kk;
+        if (k < K) {
+            const float4 w = wp[(long long)k * NV];
+            const float x0 = x[k], x1 = x[xs + k], x2 = x[2 * xs + k];
+            a0.x = fmaf(x0, w.x, a0.x); a0.y = fmaf(x0, w.y, a0.y); a0.z = fmaf(x0, w.z, a0.z); a0.w = fmaf(x0, w.w, a0.w);
+            a1.x = fmaf(x1, w.x, a1.x); a1.y = fmaf(x1, w.y, a1.y); a1.z = fmaf(x1, w.z, a1.z); a1.w = fmaf(x1, w.w, a1.w);
+            a2.x = fmaf(x2, w.x, a2.x); a2.y = fmaf(x2, w.y, a2.y); a2.z = fmaf(x2, w.z, a2.z); a2.w = fmaf(x2, w.w, a2.w);
         }
-        out[n] = a0;
-        out[os + n] = a1;
-        out[2 * os + n] = a2;
     }
+    float4* p = reinterpret_cast<float4*>(s.part + (long long)ks * 3 * N) + cq;
+    p[0] = a0;
+    p[NV] = a1;
+    p[2 * NV] = a2;
 }
 
-// N = 128: the two halves of the workgroup each take half of K; partials land in s.part.
-template <int K>
-__device__ __forceinline__ void linear_n128_partial(const float* __restrict__ Wt, const float* x, int xs, Smem& s) {
-    const int n = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const int kb = half * (K / 2);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-    for (int k = kb; k < kb + K / 2; k += 4) {
-        const float4 x0 = *reinterpret_cast<const float4*>(x + k);
-        const float4 x1 = *reinterpret_cast<const float4*>(x + xs + k);
-        const float4 x2 = *reinterpret_cast<const float4*>(x + 2 * xs + k);
-        const float w0 = Wt[(k + 0) * DIM + n], w1 = Wt[(k + 1) * DIM + n];
-        const float w2 = Wt[(k + 2) * DIM + n], w3 = Wt[(k + 3) * DIM + n];
-        a0 = fmaf(x0.x, w0, a0); a0 = fmaf(x0.y, w1, a0); a0 = fmaf(x0.z, w2, a0); a0 = fmaf(x0.w, w3, a0);
-        a1 = fmaf(x1.x, w0, a1); a1 = fmaf(x1.y, w1, a1); a1 = fmaf(x1.z, w2, a1); a1 = fmaf(x1.w, w3, a1);
-        a2 = fmaf(x2.x, w0, a2); a2 = fmaf(x2.y, w1, a2); a2 = fmaf(x2.z, w2, a2); a2 = fmaf(x2.w, w3, a2);
+// out[m*os + n] (+)= sum_ks part[ks][m][n]
+template <int K, int N, bool ACCUM>
+__device__ __forceinline__ void reduce3(Smem& s, float* out, int os) {
+    constexpr int NV = N / 4;
+    constexpr int KS = NT / NV;
+    for (int o = threadIdx.x; o < NTOK * N; o += NT) {
+        const int m = o / N, n = o - m * N;
+        float a = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a += s.part[(ks * 3 + m) * N + n];
+        if (ACCUM) out[m * os + n] += a; else out[m * os + n] = a;
     }
-    s.part[half][0][n] = a0;
-    s.part[half][1][n] = a1;
-    s.part[half][2][n] = a2;
 }
 
 // dalle2 LayerNorm (gain only, biased variance, eps 1e-5; `stable` divides by the row max first) of the
@@ -103,10 +104,12 @@ __device__ void denoise(const AviPriorWeights& w, Smem& s) {
         // ---- attention (pre-LN, multi-query, cosine-sim, rotary, null kv, T5 bias)
         layernorm3(s.tok, L.norm_g, false, s.xn);
         __syncthreads();
-        linear_wide<DIM>(L.wqkv, INNER + 2 * DH, &s.xn[0][0], DIM, &s.big[0][0], 2 * FFI);
+        linear3_partial<DIM, INNER + 2 * DH>(L.wqkv, &s.xn[0][0], DIM, s);
+        __syncthreads();
+        reduce3<DIM, INNER + 2 * DH, false>(s, &s.big[0][0], 2 * FFI);
         __syncthreads();
         // 24 query vectors + 3 keys + null key: rotary (first 32 dims, interleaved pairs), l2norm, * sqrt(16)
-        for (int vix = wave; vix < HEADS * NTOK + 4; vix += 4) {
+        for (int vix = wave; vix < HEADS * NTOK + 4; vix += NT / 64) {
             float x;
             int pos = -1;
             float* dst;
@@ -159,12 +162,9 @@ __device__ void denoise(const AviPriorWeights& w, Smem& s) {
             s.big[i][c] = p[0] * s.vv[0][d] + p[1] * s.vv[1][d] + p[2] * s.vv[2][d] + p[3] * s.vv[3][d];
         }
         __syncthreads();
-        linear_n128_partial<INNER>(L.wout, &s.big[0][0], 2 * FFI, s);
+        linear3_partial<INNER, DIM>(L.wout, &s.big[0][0], 2 * FFI, s);
         __syncthreads();
-        for (int o = tid; o < NTOK * DIM; o += NT) {
-            const int m = o >> 7, n = o & 127;
-            s.xn[m][n] = s.part[0][m][n] + s.part[1][m][n];
-        }
+        reduce3<INNER, DIM, false>(s, &s.xn[0][0], DIM);
         __syncthreads();
         layernorm3(s.xn, L.out_g, false, s.xn);   // to_out = Linear -> LayerNorm
         __syncthreads();
@@ -173,26 +173,27 @@ __device__ void denoise(const AviPriorWeights& w, Smem& s) {
         // ---- feed-forward (LayerNorm -> Linear 128->1024 -> SwiGLU -> Linear 512->128)
         layernorm3(s.tok, L.ff_g, false, s.xn);
         __syncthreads();
-        linear_wide<DIM>(L.w1, 2 * FFI, &s.xn[0][0], DIM, &s.big[0][0], 2 * FFI);
+        linear3_partial<DIM, 2 * FFI>(L.w1, &s.xn[0][0], DIM, s);
+        __syncthreads();
+        reduce3<DIM, 2 * FFI, false>(s, &s.big[0][0], 2 * FFI);
         __syncthreads();
         for (int o = tid; o < NTOK * FFI; o += NT) {
             const int m = o / FFI, c = o - m * FFI;
             s.att[m][c] = s.big[m][c] * silu(s.big[m][FFI + c]);
         }
         __syncthreads();
-        linear_n128_partial<FFI>(L.w2, &s.att[0][0], INNER, s);
+        linear3_partial<FFI, DIM>(L.w2, &s.att[0][0], INNER, s);
         __syncthreads();
-        for (int o = tid; o < NTOK * DIM; o += NT) {
-            const int m = o >> 7, n = o & 127;
-            s.tok[m][n] += s.part[0][m][n] + s.part[1][m][n];
-        }
+        reduce3<FFI, DIM, true>(s, &s.tok[0][0], DIM);
         __syncthreads();
     }
     layernorm3(s.tok, w.final_g, true, s.xn);
     __syncthreads();
-    linear_n128_partial<DIM>(w.wproj, &s.xn[0][0], DIM, s);
+    linear3_partial<DIM, DIM>(w.wproj, &s.xn[0][0], DIM, s);
     __syncthreads();
-    if (tid < DIM) s.tmp[tid] = s.part[0][2][tid] + s.part[1][2][tid];  // last token = predicted style
+    reduce3<DIM, DIM, false>(s, &s.xn[0][0], DIM);
+    __syncthreads();
+    if (tid < DIM) s.tmp[tid] = s.xn[2][tid];  // last token = predicted style
     __syncthreads();
 }
 
@@ -201,14 +202,14 @@ __device__ void time_embed(const AviPriorWeights& w, int t, Smem& s) {
     const int tid = threadIdx.x;
     if (tid < DIM) s.tmp[tid] = w.time_table[t * DIM + tid];
     __syncthreads();
-    {
+    if (tid < 256) {
         float a = w.t_b0[tid];
 #pragma unroll 8
         for (int k = 0; k < DIM; ++k) a = fmaf(s.tmp[k], w.t_w0[k * 256 + tid], a);
         s.big[0][tid] = silu(a);
     }
     __syncthreads();
-    {
+    if (tid < 256) {
         float a = w.t_b1[tid];
 #pragma unroll 8
         for (int k = 0; k < 256; ++k) a = fmaf(s.big[0][k], w.t_w1[k * 256 + tid], a);

@@ -1,0 +1,71 @@
+"""Sampling pipeline of the reference entry point (``train_diffusion_prior.py --is_test 1``, the per-utterance
+loop at :689-771) as one batched, graph-capturable pass:
+
+    int16 PCM (B, T*640) --normalise--> wav2vec2 (25 Hz) --------------------.
+    CLIP text feature (B,768) --BrainNetwork--> text_embed --100-step DDPM--> style (B,1,128)
+                                                                              |
+    audio features + style --EMOTE head + FLINT decoder--> expression (B,T,50) | jaw (B,T,3)
+
+Differences from the reference loop that do not change results: utterances are batched (the
+reference runs batch 1), wav2vec2 runs once per utterance (the reference runs it twice,
+train_diffusion_prior.py:696 vs :764), no host syncs (NaN sweeps, .item()) and no per-step Python in
+the DDPM loop; the prior is sampled on a second HIP stream concurrently with the audio encoder.
+"""
+import torch
+
+from .. import ops
+from .diffusion_prior import InstructDiffusionPrior
+from .talking_head import TalkingHeadWrapper
+
+
+class SamplingPipeline:
+    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=True):
+        self.device = torch.device(device)
+        self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
+        self.prior = InstructDiffusionPrior.from_state_dict(prior_sd, device=device, prec=prec)
+        self.side = torch.cuda.Stream(device=self.device)
+        self._graph = None
+        self._static = None
+
+    def voxel2style_emb(self, voxel, noise):
+        """train_diffusion_prior.py:783-853: voxel (B,768) -> sampled style embedding (B,1,128)."""
+        clip_voxels, _ = self.prior.voxel2clip(voxel)
+        B = voxel.shape[0]
+        return self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
+                                        cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
+                                        noise=noise)
+
+    def run(self, pcm, voxel, noise):
+        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128)
+        -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
+        B, N = pcm.shape
+        T = N // 640
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            style = self.voxel2style_emb(voxel, noise)
+        sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
+        cur.wait_stream(self.side)
+        out = self.talking_head.head(sample["audio_feature"], style)
+        out["style_emb"] = style
+        return out
+
+    # ---- hipGraph capture of the whole pass (static input buffers, replayed per batch)
+    def capture(self, pcm, voxel, noise, warmup=2):
+        self._static = (pcm.clone(), voxel.clone(), noise.clone())
+        for _ in range(warmup):
+            self.run(*self._static)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self.run(*self._static)
+        return self
+
+    def replay(self, pcm=None, voxel=None, noise=None):
+        if self._graph is None:
+            raise RuntimeError("capture() first")
+        for dst, src in zip(self._static, (pcm, voxel, noise)):
+            if src is not None:
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._out
