@@ -160,7 +160,8 @@ template <int MAXV>  // MAXV float4 per lane held in registers: C <= 256*MAXV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int rows, int C,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int act,
-                                                         const float* residual, float* out) {
+                                                         const float* __restrict__ mask, const float* residual,
+                                                         int stable, float* out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* x = in + (long long)row * C;
@@ -171,8 +172,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
         v[i] = idx < nv ? reinterpret_cast<const float4*>(x)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
+    if (stable) {  // dalle2 LayerNorm(stable=True): x / x.amax(-1) first
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < nv) mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        const float inv = 1.f / wave_max(mx);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) { v[i].x *= inv; v[i].y *= inv; v[i].z *= inv; v[i].w *= inv; }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mean = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
@@ -197,6 +208,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
             r.y = avi_act((v[i].y - mean) * rstd * g.y + bb.y, act);
             r.z = avi_act((v[i].z - mean) * rstd * g.z + bb.z, act);
             r.w = avi_act((v[i].w - mean) * rstd * g.w + bb.w, act);
+            if (mask) {  // dropout keep-mask, already scaled by 1/(1-p)
+                const float4 mk = reinterpret_cast<const float4*>(mask + (long long)row * C)[idx];
+                r.x *= mk.x; r.y *= mk.y; r.z *= mk.z; r.w *= mk.w;
+            }
             if (residual) {
                 const float4 rr = reinterpret_cast<const float4*>(residual + (long long)row * C)[idx];
                 r.x += rr.x; r.y += rr.y; r.z += rr.z; r.w += rr.w;
@@ -379,16 +394,24 @@ extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int 
     return avi_launch_status();
 }
 
-extern "C" int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
-                                 int act, const float* residual, float* out, void* stream) {
+extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                                int act, const float* mask, const float* residual, int stable, float* out,
+                                void* stream) {
     if (!in || !out || rows <= 0 || C <= 0 || (C & 3) || C > 4096) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, residual, out);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
+                           stable, out);
     else
-        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, residual, out);
+        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
+                           stable, out);
     return avi_launch_status();
+}
+
+extern "C" int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                                 int act, const float* residual, float* out, void* stream) {
+    return avi_layernorm_ex(in, rows, C, gamma, beta, eps, act, nullptr, residual, 0, out, stream);
 }
 
 extern "C" int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,

@@ -1,0 +1,420 @@
+"""Training step of the reference entry point (``train_diffusion_prior.py:434-499``) on the HIP kernels:
+
+    voxel (B,768) --BrainNetwork (train: dropout 0.5/0.15)--> clip_voxels (B,128), proj (B,1,128)
+    loss_prior, pred = diffusion_prior(text_embed=clip_voxels, image_embed=clip_target)      (:449, p_losses)
+    loss_nce = soft_clip_loss(normalize(proj), normalize(clip_target), temp)                 (:454-469)
+    loss = loss_nce + 30 * loss_prior ; backward ; AdamW (4 groups: wd 1e-2 / 0 by name)     (:474-486,997-1004)
+
+Everything numeric runs behind the C ABI: forward/backward GEMMs on the bf16x3 MFMA kernel (dX = dY.W with a
+packed W^T, dW = dY^T.X with transposed activations), fused LayerNorm(+GELU+dropout) backward, the 3-token
+attention backward, the two losses and a fused flat AdamW that also emits the bf16 hi/lo weight planes.
+Parameters, gradients and Adam moments live in flat fp32 buffers (one all-reduce-able gradient buffer; RCCL
+buckets are slices of it in backward-completion order).
+
+The random draws of the reference step (timesteps, noise, cond-drop masks, dropout masks) are inputs, so the
+step is reproducible against the oracle; ``draw()`` produces them with torch's device RNG.
+"""
+import math
+
+import torch
+
+from .. import lib as L
+from .. import ops
+from .diffusion_prior import _rel_pos_bias_table, _rotary_tables, _time_table, cosine_schedule
+
+DIM = 128
+
+
+def no_decay(name):
+    """train_diffusion_prior.py:997-1003 (substring match on parameter names)."""
+    return any(nd in name for nd in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
+
+
+class _Lin:
+    """One Linear layer y = x W^T (+ b) with weights in the flat store."""
+
+    def __init__(self, store, wname, bname=None, need_dx=True, rows=None):
+        self.s = store
+        self.w = wname
+        self.b = bname
+        self.N, self.K = rows or store.shape[wname]
+        self.need_dx = need_dx
+        if need_dx:
+            dev = store.P.device
+            self.hiT = torch.empty((self.K, self.N), dtype=torch.int16, device=dev)
+            self.loT = torch.empty_like(self.hiT)
+            self._tmp = torch.empty((self.K, self.N), dtype=torch.float32, device=dev)
+
+    def refresh_transposed(self):
+        if not self.need_dx:
+            return
+        so = L.load()
+        L.check(so.avi_transpose(self.s.ptr(self.w), self.N, self.K, self._tmp.data_ptr(), L.stream_ptr()), "transpose")
+        L.check(so.avi_pack_weight_split(self._tmp.data_ptr(), self.K, self.N, self.K, self.hiT.data_ptr(),
+                                         self.loT.data_ptr(), L.stream_ptr()), "pack")
+
+    def fwd(self, x, act=ops.ACT_NONE):
+        M = x.numel() // self.K
+        y = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
+        ops.gemm_raw(A=x.data_ptr(), lda=self.K, Whi=self.s.hi_ptr(self.w), Wlo=self.s.lo_ptr(self.w), C_=y.data_ptr(),
+                     ldc=self.N, M=M, N=self.N, K=self.K, bias=self.s.ptr(self.b) if self.b else 0, act=act)
+        return y
+
+    def bwd(self, x, dy, dx_residual=None):
+        """Accumulate nothing: writes dW (and db) into the flat gradient buffer, returns dx (+ residual)."""
+        so = L.load()
+        M = dy.numel() // self.N
+        if M % 64:
+            raise ValueError("training batch rows must be a multiple of 64")
+        dev = dy.device
+        dyT = torch.empty((self.N, M), dtype=torch.float32, device=dev)
+        xT = torch.empty((self.K, M), dtype=torch.float32, device=dev)
+        L.check(so.avi_transpose(dy.data_ptr(), M, self.N, dyT.data_ptr(), L.stream_ptr()), "transpose")
+        L.check(so.avi_transpose(x.data_ptr(), M, self.K, xT.data_ptr(), L.stream_ptr()), "transpose")
+        xT_pack = ops.PackedWeight(xT)                       # [K][M] hi/lo: the "weight" operand of the dW GEMM
+        ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xT_pack.hi.data_ptr(), Wlo=xT_pack.lo.data_ptr(),
+                     C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
+        if self.b:
+            L.check(so.avi_colsum(dy.data_ptr(), M, self.N, self.s.gptr(self.b), 0, L.stream_ptr()), "colsum")
+        if not self.need_dx:
+            return None
+        dx = torch.empty((M, self.K), dtype=torch.float32, device=dev)
+        ops.gemm_raw(A=dy.data_ptr(), lda=self.N, Whi=self.hiT.data_ptr(), Wlo=self.loT.data_ptr(), C_=dx.data_ptr(),
+                     ldc=self.K, M=M, N=self.K, K=self.N, R=L.ptr(dx_residual), ldr=self.K)
+        return dx
+
+
+class ParamStore:
+    """Flat fp32 parameter / gradient / Adam-moment buffers with named views; decay region first."""
+
+    def __init__(self, state_dict, device, order):
+        names = [n for n in order if n in state_dict]
+        missing = [n for n in state_dict if n not in names and state_dict[n].is_floating_point()
+                   and not n.startswith("noise_scheduler")]
+        if missing:
+            raise ValueError(f"parameters without a slot in the flat layout: {missing[:4]}...")
+        dec = [n for n in names if not no_decay(n)]
+        nod = [n for n in names if no_decay(n)]
+        self.offset, self.shape = {}, {}
+        off = 0
+        for group in (dec, nod):
+            for n in group:
+                t = state_dict[n]
+                self.offset[n], self.shape[n] = off, tuple(t.shape)
+                off += (t.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+            if group is dec:
+                self.n_decay = off                        # [0, n_decay): weight decay; [n_decay, numel): none
+        self.numel = off
+        self.names = dec + nod
+        self.P = torch.zeros(off, dtype=torch.float32, device=device)
+        for n in self.names:
+            self.view(n).copy_(state_dict[n].to(device, torch.float32))
+        self.G = torch.zeros_like(self.P)
+        self.M = torch.zeros_like(self.P)
+        self.V = torch.zeros_like(self.P)
+        self.HI = torch.zeros(off, dtype=torch.int16, device=device)
+        self.LO = torch.zeros_like(self.HI)
+        L.check(L.load().avi_pack_weight_split(self.P.data_ptr(), 1, off, 1, self.HI.data_ptr(), self.LO.data_ptr(),
+                                               L.stream_ptr()), "pack")
+
+    def view(self, n, buf=None):
+        buf = self.P if buf is None else buf
+        o = self.offset[n]
+        return buf[o:o + math.prod(self.shape[n])].view(self.shape[n])
+
+    def grad(self, n):
+        return self.view(n, self.G)
+
+    def ptr(self, n):
+        return self.P.data_ptr() + 4 * self.offset[n]
+
+    def gptr(self, n):
+        return self.G.data_ptr() + 4 * self.offset[n]
+
+    def hi_ptr(self, n):
+        return self.HI.data_ptr() + 2 * self.offset[n]
+
+    def lo_ptr(self, n):
+        return self.LO.data_ptr() + 2 * self.offset[n]
+
+    def state_dict(self):
+        return {n: self.view(n).detach().clone() for n in self.names}
+
+
+def _layout(depth=6, n_blocks=4):
+    """Flat order = reverse of backward completion, so gradient buckets finish front-to-back... kept simple:
+    aligner first, prior after; fused matrices (to_q | to_kv) adjacent."""
+    v, n = "voxel2clip.", "net."
+    order = [v + "lin0.0.weight", v + "lin0.0.bias", v + "lin0.1.weight", v + "lin0.1.bias"]
+    for b in range(n_blocks):
+        order += [v + f"mlp.{b}.0.weight", v + f"mlp.{b}.0.bias", v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias"]
+    order += [v + "lin1.weight", v + "lin1.bias"]
+    for i in (0, 2, 3, 5, 6, 8):
+        order += [v + f"projector.{i}.weight", v + f"projector.{i}.bias"]
+    t = n + "to_time_embeds.0.1.net."
+    order += [t + "0.0.weight", t + "0.0.bias", t + "1.0.weight", t + "1.0.bias", t + "2.weight", t + "2.bias",
+              n + "learned_query", n + "null_brain_embeds", n + "null_image_embed"]
+    c = n + "causal_transformer."
+    order += [c + "rel_pos_bias.relative_attention_bias.weight"]
+    for l in range(depth):
+        a, f = c + f"layers.{l}.0.", c + f"layers.{l}.1."
+        order += [a + "norm.g", a + "to_q.weight", a + "to_kv.weight", a + "null_kv", a + "to_out.0.weight",
+                  a + "to_out.1.g", f + "0.g", f + "1.weight", f + "5.weight"]
+    order += [c + "norm.g", c + "project_out.weight"]
+    return order
+
+
+class PriorTrainer:
+    def __init__(self, state_dict, device="cuda", lr=1e-4, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8,
+                 timesteps=100, prior_mult=30.0, depth=6, n_blocks=4, process_group=None):
+        self.device = torch.device(device)
+        self.depth, self.n_blocks = depth, n_blocks
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.prior_mult = prior_mult
+        self.step_count = 0
+        self.pg = process_group
+        self.store = S = ParamStore(state_dict, self.device, _layout(depth, n_blocks))
+        v, n = "voxel2clip.", "net."
+        self.lin0 = _Lin(S, v + "lin0.0.weight", v + "lin0.0.bias", need_dx=False)
+        self.mlp = [_Lin(S, v + f"mlp.{b}.0.weight", v + f"mlp.{b}.0.bias") for b in range(n_blocks)]
+        self.lin1 = _Lin(S, v + "lin1.weight", v + "lin1.bias")
+        self.proj = [_Lin(S, v + f"projector.{i}.weight", v + f"projector.{i}.bias") for i in (2, 5, 8)]
+        t = n + "to_time_embeds.0.1.net."
+        self.tm = [_Lin(S, t + "0.0.weight", t + "0.0.bias", need_dx=False), _Lin(S, t + "1.0.weight", t + "1.0.bias"),
+                   _Lin(S, t + "2.weight", t + "2.bias")]
+        c = n + "causal_transformer."
+        self.layers = []
+        for l in range(depth):
+            a, f = c + f"layers.{l}.0.", c + f"layers.{l}.1."
+            self.layers.append(dict(
+                a=a, f=f,
+                qkv=_Lin(S, a + "to_q.weight", rows=(640, DIM)),            # to_q | to_kv are adjacent in the store
+                out=_Lin(S, a + "to_out.0.weight"), w1=_Lin(S, f + "1.weight"), w2=_Lin(S, f + "5.weight")))
+            assert S.offset[a + "to_kv.weight"] == S.offset[a + "to_q.weight"] + 512 * DIM
+        self.cproj = _Lin(S, c + "project_out.weight")
+        self.c = c
+        self.lins = ([self.lin0, self.lin1] + self.mlp + self.proj + self.tm + [self.cproj] +
+                     [ly[k] for ly in self.layers for k in ("qkv", "out", "w1", "w2")])
+        sched = cosine_schedule(timesteps)
+        dv = lambda x: x.to(self.device).contiguous()
+        self.sqrt_ac, self.sqrt_1mac = dv(sched["sqrt_alphas_cumprod"]), dv(sched["sqrt_one_minus_alphas_cumprod"])
+        self.time_table = dv(_time_table(timesteps))
+        rc, rs = _rotary_tables(3)
+        self.rot_cos, self.rot_sin = dv(rc), dv(rs)
+        q = torch.arange(3)[:, None]
+        k = torch.arange(4)[None, :]
+        self.rel_index = dv(torch.clamp(q - k, min=0))                        # (3,4) bucket of each (i,j)
+        self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
+        self.refresh()
+
+    # ------------------------------------------------------------------ helpers
+    def refresh(self):
+        for lin in self.lins:
+            lin.refresh_transposed()
+
+    def _ln(self, x, g, b=None, act=ops.ACT_NONE, mask=None, residual=None, stable=0):
+        S = self.store
+        out = torch.empty_like(x)
+        C = x.shape[-1]
+        L.check(L.load().avi_layernorm_ex(x.data_ptr(), x.numel() // C, C, S.ptr(g), S.ptr(b) if b else 0, 1e-5, act,
+                                          L.ptr(mask), L.ptr(residual), stable, out.data_ptr(), L.stream_ptr()), "ln")
+        return out
+
+    def _ln_bwd(self, x, dy, g, b=None, act=ops.ACT_NONE, mask=None, stable=0, dx_add=None):
+        S = self.store
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dx = torch.empty_like(x)
+        stats = torch.empty(3 * rows, dtype=torch.float32, device=x.device)
+        L.check(L.load().avi_layernorm_bwd(x.data_ptr(), dy.data_ptr(), S.ptr(g), S.ptr(b) if b else 0, L.ptr(mask),
+                                           rows, C, 1e-5, act, stable, L.ptr(dx_add), dx.data_ptr(), S.gptr(g),
+                                           S.gptr(b) if b else 0, 0, stats.data_ptr(), L.stream_ptr()), "ln_bwd")
+        return dx
+
+    def draw(self, B, generator=None):
+        """The random inputs of one reference step: times (sample_random_times), noise, cond-drop keep masks
+        (prob_mask_like(1 - 0.2)), dropout keep masks scaled by 1/(1-p)."""
+        dev = self.device
+        r = lambda *s: torch.rand(*s, device=dev, generator=generator)
+        masks = [(r(B, 4096) >= 0.5).float() / 0.5] + [(r(B, 4096) >= 0.15).float() / 0.85 for _ in range(self.n_blocks)]
+        return dict(times=torch.randint(0, 100, (B,), device=dev, generator=generator).to(torch.int32),
+                    noise=torch.randn(B, DIM, device=dev, generator=generator),
+                    brain_keep=(r(B) < 0.8).to(torch.uint8), image_keep=(r(B) < 0.8).to(torch.uint8),
+                    dropout_masks=masks)
+
+    # ------------------------------------------------------------------ forward + backward
+    def forward_backward(self, voxel, clip_target, times, noise, temp, brain_keep=None, image_keep=None,
+                         dropout_masks=None):
+        so = L.load()
+        S, dev = self.store, self.device
+        B = voxel.shape[0]
+        R = 3 * B
+        st = L.stream_ptr
+        v = "voxel2clip."
+        x = voxel.to(dev, torch.float32).contiguous()
+        target = clip_target.reshape(B, DIM).to(dev, torch.float32).contiguous()
+        dm = dropout_masks or [None] * (self.n_blocks + 1)
+        S.G.zero_()
+
+        # ---- BrainNetwork forward (models/diffusion_prior.py:95-117, train mode)
+        h0p = self.lin0.fwd(x)
+        h = [self._ln(h0p, v + "lin0.1.weight", v + "lin0.1.bias", ops.ACT_GELU, dm[0])]
+        yp = []
+        for b in range(self.n_blocks):
+            yp.append(self.mlp[b].fwd(h[b]))
+            h.append(self._ln(yp[b], v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias", ops.ACT_GELU, dm[b + 1], h[b]))
+        out = self.lin1.fwd(h[-1])                                            # clip_voxels (B,128)
+        z0 = self._ln(out, v + "projector.0.weight", v + "projector.0.bias", ops.ACT_GELU)
+        z1p = self.proj[0].fwd(z0)
+        z1 = self._ln(z1p, v + "projector.3.weight", v + "projector.3.bias", ops.ACT_GELU)
+        z2p = self.proj[1].fwd(z1)
+        z2 = self._ln(z2p, v + "projector.6.weight", v + "projector.6.bias", ops.ACT_GELU)
+        proj = self.proj[2].fwd(z2)
+
+        # ---- prior forward (p_losses, models/diffusion_prior.py:369-400)
+        t32 = times.to(dev, torch.int32).contiguous()
+        te0 = self.time_table.index_select(0, t32.long())
+        a1p = self.tm[0].fwd(te0)
+        a1 = torch.empty_like(a1p)
+        L.check(so.avi_act_fwd(a1p.data_ptr(), a1p.numel(), ops.ACT_SILU, a1.data_ptr(), st()), "act")
+        a2p = self.tm[1].fwd(a1)
+        a2 = torch.empty_like(a2p)
+        L.check(so.avi_act_fwd(a2p.data_ptr(), a2p.numel(), ops.ACT_SILU, a2.data_ptr(), st()), "act")
+        temb = self.tm[2].fwd(a2)
+        nz = noise.reshape(B, DIM).to(dev, torch.float32).contiguous()
+        bk = None if brain_keep is None else brain_keep.to(dev, torch.uint8).contiguous()
+        ik = None if image_keep is None else image_keep.to(dev, torch.uint8).contiguous()
+        x0 = torch.empty((B, DIM), dtype=torch.float32, device=dev)
+        tok = torch.empty((R, DIM), dtype=torch.float32, device=dev)
+        L.check(so.avi_prior_tokens_fwd(target.data_ptr(), nz.data_ptr(), t32.data_ptr(), self.sqrt_ac.data_ptr(),
+                                        self.sqrt_1mac.data_ptr(), DIM ** 0.5, out.data_ptr(), temb.data_ptr(),
+                                        L.ptr(bk), L.ptr(ik), S.ptr("net.null_brain_embeds"),
+                                        S.ptr("net.null_image_embed"), S.ptr("net.learned_query"), B, x0.data_ptr(),
+                                        tok.data_ptr(), st()), "tokens_fwd")
+        rel_bias = S.view(self.c + "rel_pos_bias.relative_attention_bias.weight")[self.rel_index].permute(2, 0, 1).contiguous()
+        saved = []
+        for ly in self.layers:
+            a, f = ly["a"], ly["f"]
+            n1 = self._ln(tok, a + "norm.g")
+            qkv = ly["qkv"].fwd(n1)
+            ao = torch.empty((R, 512), dtype=torch.float32, device=dev)
+            L.check(so.avi_prior_attn_fwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
+                                          self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), B, ao.data_ptr(), st()), "attn")
+            o1 = ly["out"].fwd(ao)
+            tokm = self._ln(o1, a + "to_out.1.g", residual=tok)
+            n2 = self._ln(tokm, f + "0.g")
+            hff = ly["w1"].fwd(n2)
+            sw = torch.empty((R, 512), dtype=torch.float32, device=dev)
+            L.check(so.avi_swiglu_fwd(hff.data_ptr(), R, 512, sw.data_ptr(), st()), "swiglu")
+            tok_next = torch.empty_like(tok)
+            ops.gemm_raw(A=sw.data_ptr(), lda=512, Whi=S.hi_ptr(f + "5.weight"), Wlo=S.lo_ptr(f + "5.weight"),
+                         C_=tok_next.data_ptr(), ldc=DIM, M=R, N=DIM, K=512, R=tokm.data_ptr(), ldr=DIM)
+            saved.append((tok, n1, qkv, ao, o1, tokm, n2, hff, sw))
+            tok = tok_next
+        fin = self._ln(tok, self.c + "norm.g", stable=1)
+        po = self.cproj.fwd(fin)
+        pred = po.view(B, 3, DIM)[:, 2].contiguous()
+
+        # ---- losses (+ their gradients)
+        losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        dpred = torch.empty_like(pred)
+        L.check(so.avi_mse_loss(pred.data_ptr(), x0.data_ptr(), B * DIM, self.prior_mult, losses.data_ptr(),
+                                dpred.data_ptr(), st()), "mse")
+        dproj = torch.empty_like(proj)
+        scratch = torch.empty(2 * B * DIM + 2 * B + 3 * B * B, dtype=torch.float32, device=dev)
+        L.check(so.avi_soft_clip_loss(proj.data_ptr(), target.data_ptr(), B, DIM, float(temp), 1.0,
+                                      losses.data_ptr() + 4, dproj.data_ptr(), scratch.data_ptr(), st()), "clip")
+
+        # ---- prior backward
+        dpo = torch.zeros((B, 3, DIM), dtype=torch.float32, device=dev)
+        dpo[:, 2] = dpred
+        dfin = self.cproj.bwd(fin, dpo.view(R, DIM))
+        dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1)
+        drel = torch.zeros((8, 3, 4), dtype=torch.float32, device=dev)
+        for ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(self.layers), reversed(saved)):
+            a, f = ly["a"], ly["f"]
+            dsw = ly["w2"].bwd(sw, dtok)
+            dhff = torch.empty_like(hff)
+            L.check(so.avi_swiglu_bwd(hff.data_ptr(), dsw.data_ptr(), R, 512, dhff.data_ptr(), st()), "swiglu_bwd")
+            dn2 = ly["w1"].bwd(n2, dhff)
+            dtokm = self._ln_bwd(tokm, dn2, f + "0.g", dx_add=dtok)
+            do1 = self._ln_bwd(o1, dtokm, a + "to_out.1.g")
+            dao = ly["out"].bwd(ao, do1)
+            dqkv = torch.empty_like(qkv)
+            L.check(so.avi_prior_attn_bwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
+                                          self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), dao.data_ptr(), B,
+                                          dqkv.data_ptr(), S.gptr(a + "null_kv"), drel.data_ptr(), st()), "attn_bwd")
+            dn1 = ly["qkv"].bwd(n1, dqkv)
+            dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm)
+        # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
+        gemb = S.grad(self.c + "rel_pos_bias.relative_attention_bias.weight")
+        gemb.index_put_((self.rel_index.reshape(-1),), drel.permute(1, 2, 0).reshape(12, 8), accumulate=True)
+        dtext = torch.empty((B, DIM), dtype=torch.float32, device=dev)
+        dtemb = torch.empty((B, DIM), dtype=torch.float32, device=dev)
+        L.check(so.avi_prior_tokens_bwd(dtok.data_ptr(), L.ptr(bk), L.ptr(ik), B, dtext.data_ptr(), dtemb.data_ptr(),
+                                        S.gptr("net.null_brain_embeds"), S.gptr("net.null_image_embed"),
+                                        S.gptr("net.learned_query"), st()), "tokens_bwd")
+        da2 = self.tm[2].bwd(a2, dtemb)
+        da2p = torch.empty_like(a2p)
+        L.check(so.avi_act_bwd(a2p.data_ptr(), da2.data_ptr(), a2p.numel(), ops.ACT_SILU, da2p.data_ptr(), st()), "act_bwd")
+        da1 = self.tm[1].bwd(a1, da2p)
+        da1p = torch.empty_like(a1p)
+        L.check(so.avi_act_bwd(a1p.data_ptr(), da1.data_ptr(), a1p.numel(), ops.ACT_SILU, da1p.data_ptr(), st()), "act_bwd")
+        self.tm[0].bwd(te0, da1p)
+
+        # ---- BrainNetwork backward
+        dz2 = self.proj[2].bwd(z2, dproj)
+        dz2p = self._ln_bwd(z2p, dz2, v + "projector.6.weight", v + "projector.6.bias", ops.ACT_GELU)
+        dz1 = self.proj[1].bwd(z1, dz2p)
+        dz1p = self._ln_bwd(z1p, dz1, v + "projector.3.weight", v + "projector.3.bias", ops.ACT_GELU)
+        dz0 = self.proj[0].bwd(z0, dz1p)
+        dout = self._ln_bwd(out, dz0, v + "projector.0.weight", v + "projector.0.bias", ops.ACT_GELU, dx_add=dtext)
+        dh = self.lin1.bwd(h[-1], dout)
+        for b in reversed(range(self.n_blocks)):
+            dyp = self._ln_bwd(yp[b], dh, v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias", ops.ACT_GELU, dm[b + 1])
+            dh = self.mlp[b].bwd(h[b], dyp, dx_residual=dh)
+        dh0p = self._ln_bwd(h0p, dh, v + "lin0.1.weight", v + "lin0.1.bias", ops.ACT_GELU, dm[0])
+        self.lin0.bwd(x, dh0p)
+        return {"loss_prior": losses[0:1], "loss_nce": losses[1:2], "pred": pred, "proj": proj, "clip_voxels": out}
+
+    # ------------------------------------------------------------------ optimizer
+    def allreduce_grads(self, n_buckets=8):
+        """DP: sum gradients over ranks (RCCL all-reduce over xGMI; gloo in CPU tests).  The flat buffer is cut into
+        buckets so the collective pipelines; AdamW then scales by 1/world."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+            return 1
+        n = self.store.numel
+        step = (n + n_buckets - 1) // n_buckets // 4 * 4
+        works = []
+        for o in range(0, n, step):
+            works.append(dist.all_reduce(self.store.G[o:o + step], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        return dist.get_world_size(self.pg)
+
+    def optimizer_step(self, lr=None, world=1, use_dyn=False):
+        S = self.store
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        b1, b2 = self.betas
+        if use_dyn:
+            self.dyn.copy_(torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), 0.0]),
+                           non_blocking=True)
+        dyn = self.dyn.data_ptr() if use_dyn else 0
+        so = L.load()
+        for lo, hi_, wd in ((0, S.n_decay, self.wd), (S.n_decay, S.numel, 0.0)):
+            if hi_ > lo:
+                L.check(so.avi_adamw(S.P.data_ptr() + 4 * lo, S.G.data_ptr() + 4 * lo, S.M.data_ptr() + 4 * lo,
+                                     S.V.data_ptr() + 4 * lo, hi_ - lo, lr, b1, b2, self.eps, wd, self.step_count,
+                                     1.0 / world, dyn, S.HI.data_ptr() + 2 * lo, S.LO.data_ptr() + 2 * lo,
+                                     L.stream_ptr()), "adamw")
+        self.refresh()
+
+    def train_step(self, voxel, clip_target, temp, rand=None, lr=None):
+        rand = rand or self.draw(voxel.shape[0])
+        out = self.forward_backward(voxel, clip_target, rand["times"], rand["noise"], temp, rand["brain_keep"],
+                                    rand["image_keep"], rand["dropout_masks"])
+        world = self.allreduce_grads()
+        self.optimizer_step(lr, world)
+        return out

@@ -71,6 +71,21 @@ SIGNATURES = {
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
+    "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "avi_transpose": [_vp, _i, _i, _vp, _vp],
+    "avi_colsum": [_vp, _i, _i, _vp, _i, _vp],
+    "avi_act_fwd": [_vp, _ll, _i, _vp, _vp],
+    "avi_act_bwd": [_vp, _vp, _ll, _i, _vp, _vp],
+    "avi_swiglu_fwd": [_vp, _i, _i, _vp, _vp],
+    "avi_swiglu_bwd": [_vp, _vp, _i, _i, _vp, _vp],
+    "avi_prior_tokens_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "avi_prior_tokens_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "avi_prior_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "avi_prior_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "avi_mse_loss": [_vp, _vp, _i, _f, _vp, _vp, _vp],
+    "avi_soft_clip_loss": [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "avi_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

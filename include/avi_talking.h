@@ -193,6 +193,60 @@ typedef struct AviFaceformerWeights {
 int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
                           float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step (aligner + prior; train_diffusion_prior.py:434-499).  Backward GEMMs reuse avi_gemm:
+ *   dX = dY . W      -> avi_gemm(A = dY, W = packed W^T)
+ *   dW = dY^T . X    -> avi_gemm(A = dY^T (avi_transpose), W = packed X^T), bias grad = avi_colsum(dY).
+ * ---------------------------------------------------------------------------------------- */
+/* LayerNorm with everything the training forward needs: y = act(LN(x / amax if stable)) * mask + residual.
+ * mask = dropout keep-mask pre-scaled by 1/(1-p) or NULL; beta NULL = gain-only (dalle2 LayerNorm). */
+int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const float* beta, float eps, int act,
+                     const float* mask, const float* residual, int stable, float* out, void* stream);
+/* Backward of the above w.r.t. x, gamma, beta (residual passes through at the caller).
+ * stats: scratch >= 3*rows floats.  accumulate != 0 adds into dgamma/dbeta.  dbeta may be NULL. */
+int avi_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mask,
+                      int rows, int C, float eps, int act, int stable, const float* dx_add, float* dx, float* dgamma,
+                      float* dbeta, int accumulate, float* stats, void* stream);   /* dx = dLN/dx + dx_add (or NULL) */
+int avi_transpose(const float* in, int R, int C, float* out, void* stream);                 /* [R][C] -> [C][R] */
+int avi_colsum(const float* in, int R, int C, float* out, int accumulate, void* stream);     /* out[c] = sum_r */
+int avi_act_fwd(const float* x, long long n, int act, float* y, void* stream);
+int avi_act_bwd(const float* x_pre, const float* dy, long long n, int act, float* dx, void* stream);
+/* dalle2 SwiGLU: h [R][2F] = value | gate, y [R][F] = value * silu(gate) */
+int avi_swiglu_fwd(const float* h, int R, int F, float* y, void* stream);
+int avi_swiglu_bwd(const float* h, const float* dy, int R, int F, float* dh, void* stream);
+/* q_sample + token assembly of p_losses (models/diffusion_prior.py:372,255-303):
+ * x0 = target*scale; x_t = sqrt_ac[t] x0 + sqrt_1mac[t] noise; tokens [B][3][128] = [text|null, time, x_t|null + query]. */
+int avi_prior_tokens_fwd(const float* target, const float* noise, const int* t, const float* sqrt_ac,
+                         const float* sqrt_1mac, float scale, const float* text_embed, const float* time_emb,
+                         const unsigned char* brain_keep, const unsigned char* image_keep, const float* null_brain,
+                         const float* null_image, const float* learned_query, int B, float* x0, float* tokens,
+                         void* stream);
+/* dtokens -> dtext [B][128], dtime [B][128]; dnull_brain/dnull_image/dlearned_query [128] are ADDED to. */
+int avi_prior_tokens_bwd(const float* dtokens, const unsigned char* brain_keep, const unsigned char* image_keep, int B,
+                         float* dtext, float* dtime, float* dnull_brain, float* dnull_image, float* dlearned_query,
+                         void* stream);
+/* dalle2 Attention core on 3 tokens (+ null kv): qkv [B][3][640] (q 512 | k 64 | v 64) -> out [B][3][512].
+ * Backward recomputes the forward; dnull_kv [2][64] and drel_bias [8][3][4] are ADDED to (atomics). */
+int avi_prior_attn_fwd(const float* qkv, const float* null_kv, const float* rel_bias, const float* rot_cos,
+                       const float* rot_sin, int B, float* out, void* stream);
+int avi_prior_attn_bwd(const float* qkv, const float* null_kv, const float* rel_bias, const float* rot_cos,
+                       const float* rot_sin, const float* dout, int B, float* dqkv, float* dnull_kv, float* drel_bias,
+                       void* stream);
+/* loss[0] = mean((pred-x0)^2) (models/diffusion_prior.py:391-399, predict_x_start); dpred = weight*dloss/dpred. */
+int avi_mse_loss(const float* pred, const float* x0, int n, float weight, float* loss, float* dpred, void* stream);
+/* soft_clip_loss (train_diffusion_prior.py:125-133) on L2-normalised rows (:454-455): proj/target [B][D], D <= 256.
+ * dproj = grad_scale * dloss/dproj.  scratch >= 2*B*D + 2*B + 3*B*B floats. */
+int avi_soft_clip_loss(const float* proj, const float* target, int B, int D, float temp, float grad_scale, float* loss,
+                       float* dproj, float* scratch, void* stream);
+/* Fused AdamW over one flat parameter region (torch.optim.AdamW semantics, train_diffusion_prior.py:997-1004),
+ * n % 4 == 0, step >= 1; g is multiplied by grad_scale first (1/world for DP-averaged sums).
+ * hi/lo (both or neither): also emit the bf16 hi/lo planes of the updated values for avi_gemm.
+ * dyn (device pointer or NULL): {lr, 1-beta1^step, 1/sqrt(1-beta2^step)} override the scalar arguments, so a
+ * captured hipGraph can be replayed with a new learning rate every step. */
+int avi_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, float grad_scale, const float* dyn, uint16_t* hi, uint16_t* lo,
+              void* stream);
+
 #ifdef __cplusplus
 }
 #endif
