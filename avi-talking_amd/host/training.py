@@ -30,6 +30,18 @@ def no_decay(name):
     return any(nd in name for nd in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
 
 
+def bucketed_allreduce(flat, spans, group=None, async_op=True):
+    """Sum ``flat[a:b]`` over the ranks for every (a, b) in ``spans`` (one collective per span).  With the
+    "nccl" backend (= RCCL on ROCm) an async collective is enqueued behind the work already on the current
+    stream and runs on RCCL's own stream, so later backward kernels overlap with it; returns the work handles."""
+    import torch.distributed as dist
+    works = []
+    for a, b in spans:
+        if b > a:
+            works.append(dist.all_reduce(flat[a:b], group=group, async_op=async_op))
+    return works
+
+
 class _Lin:
     """One Linear layer y = x W^T (+ b) with weights in the flat store."""
 
@@ -205,7 +217,26 @@ class PriorTrainer:
         k = torch.arange(4)[None, :]
         self.rel_index = dv(torch.clamp(q - k, min=0))                        # (3,4) bucket of each (i,j)
         self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
+        self._works = []
         self.refresh()
+
+    # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
+    def _dp_world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.pg)
+        return 1
+
+    def _span(self, first, last):
+        S = self.store
+        return (S.offset[first], S.offset[last] + math.prod(S.shape[last]))
+
+    def _grads_ready(self, first, last):
+        """Called as soon as the backward pass has finished writing the decay-region gradients from parameter
+        ``first`` through ``last`` (contiguous in the flat buffer): start their all-reduce now, so it overlaps
+        with the rest of backward (the 67 M-parameter aligner blocks dominate the 311 MB volume)."""
+        if self._dp_world() > 1:
+            self._works += bucketed_allreduce(self.store.G, [self._span(first, last)], self.pg)
 
     # ------------------------------------------------------------------ helpers
     def refresh(self):
@@ -361,6 +392,7 @@ class PriorTrainer:
         da1p = torch.empty_like(a1p)
         L.check(so.avi_act_bwd(a1p.data_ptr(), da1.data_ptr(), a1p.numel(), ops.ACT_SILU, da1p.data_ptr(), st()), "act_bwd")
         self.tm[0].bwd(te0, da1p)
+        self._grads_ready("net.to_time_embeds.0.1.net.0.0.weight", self.c + "project_out.weight")
 
         # ---- BrainNetwork backward
         dz2 = self.proj[2].bwd(z2, dproj)
@@ -370,43 +402,51 @@ class PriorTrainer:
         dz0 = self.proj[0].bwd(z0, dz1p)
         dout = self._ln_bwd(out, dz0, v + "projector.0.weight", v + "projector.0.bias", ops.ACT_GELU, dx_add=dtext)
         dh = self.lin1.bwd(h[-1], dout)
+        self._grads_ready(v + "lin1.weight", v + "projector.8.weight")
         for b in reversed(range(self.n_blocks)):
             dyp = self._ln_bwd(yp[b], dh, v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias", ops.ACT_GELU, dm[b + 1])
             dh = self.mlp[b].bwd(h[b], dyp, dx_residual=dh)
+            self._grads_ready(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight")
         dh0p = self._ln_bwd(h0p, dh, v + "lin0.1.weight", v + "lin0.1.bias", ops.ACT_GELU, dm[0])
         self.lin0.bwd(x, dh0p)
+        self._grads_ready(v + "lin0.0.weight", v + "lin0.1.weight")
         return {"loss_prior": losses[0:1], "loss_nce": losses[1:2], "pred": pred, "proj": proj, "clip_voxels": out}
 
     # ------------------------------------------------------------------ optimizer
-    def allreduce_grads(self, n_buckets=8):
-        """DP: sum gradients over ranks (RCCL all-reduce over xGMI; gloo in CPU tests).  The flat buffer is cut into
-        buckets so the collective pipelines; AdamW then scales by 1/world."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+    def allreduce_grads(self):
+        """DP: finish the gradient sum over ranks (RCCL all-reduce over xGMI).  The weight buckets were launched
+        from inside backward (``_grads_ready``); the small no-decay tail (biases, T5 table) goes last.  AdamW then
+        scales by 1/world."""
+        world = self._dp_world()
+        if world == 1:
             return 1
-        n = self.store.numel
-        step = (n + n_buckets - 1) // n_buckets // 4 * 4
-        works = []
-        for o in range(0, n, step):
-            works.append(dist.all_reduce(self.store.G[o:o + step], group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
-        return dist.get_world_size(self.pg)
-
-    def optimizer_step(self, lr=None, world=1, use_dyn=False):
         S = self.store
-        self.step_count += 1
+        self._works += bucketed_allreduce(S.G, [(S.n_decay, S.numel)], self.pg)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return world
+
+    def _set_dyn(self, lr):
+        """Step-dependent AdamW scalars go through device memory so a captured graph can be replayed."""
+        b1, b2 = self.betas
+        host = torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), 0.0])
+        self.dyn.copy_(host, non_blocking=True)
+
+    def optimizer_step(self, lr=None, world=1, use_dyn=False, _in_graph=False):
+        S = self.store
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
-        if use_dyn:
-            self.dyn.copy_(torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), 0.0]),
-                           non_blocking=True)
+        if not _in_graph:
+            self.step_count += 1
+            if use_dyn:
+                self._set_dyn(lr)
         dyn = self.dyn.data_ptr() if use_dyn else 0
         so = L.load()
         for lo, hi_, wd in ((0, S.n_decay, self.wd), (S.n_decay, S.numel, 0.0)):
             if hi_ > lo:
                 L.check(so.avi_adamw(S.P.data_ptr() + 4 * lo, S.G.data_ptr() + 4 * lo, S.M.data_ptr() + 4 * lo,
-                                     S.V.data_ptr() + 4 * lo, hi_ - lo, lr, b1, b2, self.eps, wd, self.step_count,
+                                     S.V.data_ptr() + 4 * lo, hi_ - lo, lr, b1, b2, self.eps, wd, max(self.step_count, 1),
                                      1.0 / world, dyn, S.HI.data_ptr() + 2 * lo, S.LO.data_ptr() + 2 * lo,
                                      L.stream_ptr()), "adamw")
         self.refresh()
@@ -418,3 +458,32 @@ class PriorTrainer:
         world = self.allreduce_grads()
         self.optimizer_step(lr, world)
         return out
+
+    # ------------------------------------------------------------------ hipGraph capture (single GPU)
+    def capture_step(self, voxel, clip_target, temp, rand, warmup=2):
+        """Capture forward + backward + AdamW (no collective) into one hipGraph over static input buffers."""
+        self._static = dict(voxel=voxel.clone(), target=clip_target.clone(),
+                            rand={k: ([m.clone() for m in v] if isinstance(v, list) else v.clone())
+                                  for k, v in rand.items()})
+        st = self._static
+
+        def body(in_graph):
+            r = st["rand"]
+            out = self.forward_backward(st["voxel"], st["target"], r["times"], r["noise"], temp, r["brain_keep"],
+                                        r["image_keep"], r["dropout_masks"])
+            self.optimizer_step(use_dyn=True, _in_graph=in_graph)
+            return out
+
+        for _ in range(warmup):
+            body(False)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._gout = body(True)
+        return self
+
+    def replay_step(self, lr=None):
+        self.step_count += 1
+        self._set_dyn(self.lr if lr is None else lr)
+        self._graph.replay()
+        return self._gout

@@ -58,6 +58,8 @@ def main():
                     help="bf16x3 = 3-term split bf16 MFMA (passes the 1e-3 parity gate; default); bf16 = 1 term")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train-steps", type=int, default=20)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +126,14 @@ def main():
         roofline = measure_gemm_roofline(pipe, pcm, voxel, noise, prec)
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = measure_cpu_baseline(wa, wh, wp)
+    del pipe
+    torch.cuda.empty_cache()
+    train = None
+    if not args.no_train:
+        try:
+            train = measure_train(wp, dev, world, rank, local_rank, dist, args)
+        except Exception as e:  # the sampling line above must survive a failure of the secondary measurement
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         line = {
@@ -137,11 +147,58 @@ def main():
                        "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
             "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
             "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "train": train,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_train(wp, dev, world, rank, local_rank, dist, args):
+    """BASELINE.json configs[2]/[3]: one training step of the aligner + prior (77.7 M parameters): batch 64 per GPU,
+    forward + backward + fused AdamW; N > 1 adds the RCCL all-reduce of the 311 MB fp32 gradient buffer, launched
+    bucket by bucket from inside backward.  Single GPU replays one hipGraph per step."""
+    from avi_talking_amd.host.training import PriorTrainer
+    B = 64
+    tr = PriorTrainer(wp, device=dev, lr=1e-4)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    voxel = torch.randn(B, 768, device=dev, generator=g)
+    target = torch.randn(B, 1, 128, device=dev, generator=g) * 0.3
+    rand = tr.draw(B, generator=g)
+    temp = 0.005
+    graph = world == 1 and not args.no_graph
+    if graph:
+        tr.capture_step(voxel, target, temp, rand)
+        step = tr.replay_step
+    else:
+        step = lambda: tr.train_step(voxel, target, temp, rand=rand)
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    lp, ln = float(out["loss_prior"].item()), float(out["loss_nce"].item())
+    if not (lp == lp and ln == ln):
+        raise ValueError("NaN loss")                       # train_diffusion_prior.py:135-137 check_loss
+    return {"workload": "configs[2]: aligner+prior train step, batch 64 per GPU, fwd+bwd+fused AdamW"
+                        + (", RCCL gradient all-reduce overlapped with backward" if world > 1 else ""),
+            "samples_per_s": round(world * B * args.train_steps / dt, 1), "ms_per_step": round(dt / args.train_steps * 1e3, 3),
+            "steps": args.train_steps, "global_batch": world * B, "params_m": round(tr.store.numel / 1e6, 1),
+            "allreduce_mb": round(tr.store.numel * 4 / 1e6, 1) if world > 1 else 0, "hipgraph": graph,
+            "dtype": "bf16x3", "loss_prior": round(lp, 5), "loss_nce": round(ln, 5)}
 
 
 def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):

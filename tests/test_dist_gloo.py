@@ -62,3 +62,29 @@ def test_sharded_sampling_matches_single_process():
         ref = torch.cat([o["predicted_exp"], o["predicted_jaw"]], -1)[0]
         assert ret["outs"][i].shape == (T, 53)
         assert torch.allclose(ret["outs"][i], ref, atol=1e-6)
+
+
+def _ar_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd.host.training import bucketed_allreduce
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    spans = [(600, 1000), (100, 600), (0, 100)]            # backward-completion order, covering [0, n) once
+    works = bucketed_allreduce(flat, spans, async_op=True)
+    for w in works:
+        w.wait()
+    if rank == 0:
+        ret["flat"] = flat.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce():
+    """The DP gradient sum of the training step (C1): every span of the flat gradient buffer is reduced once."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ar_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    expect = torch.arange(1000, dtype=torch.float32) * 3     # rank 0: x1, rank 1: x2
+    assert torch.equal(ret["flat"], expect)
