@@ -1,0 +1,222 @@
+// Head-dim-64, unbiased multi-head attention on the bf16 matrix cores with 3-term split operands (fp32-grade):
+// the wav2vec2 encoder's attention (HF eager attention via models/lib/wav2vec.py:142-148), 12 layers x 384 (b,h).
+//
+// Two launches per call:
+//  1. attn_prep_kernel   packed fp32 QKV [B][T][3*H*64] -> bf16 hi/lo planes
+//                          Q  [B*H][Tp][64]  (pre-multiplied by the softmax scale)
+//                          K  [B*H][Tp][64]
+//                          V^T[B*H][64][Tp]  (transposed through LDS), Tp = T rounded up to 64, zero padded.
+//  2. attn_mfma_kernel   one wave = 16 queries, flash-style loop over 64-key tiles, no LDS and no barriers:
+//        S^T = K . Q^T      (A = K rows, B = Q cols)   -> lane (q = l&15, g = l>>4) holds keys 16t + 4g + r
+//        online softmax per query (16 own values + 2 xor-shuffles across the 4 lane groups)
+//        O^T = V^T . P^T    (A = V^T rows d, B = P from the accumulator registers)
+//     The accumulator layout of S^T is already the B-operand layout of the second product once the 32 keys of a
+//     k-step are relabelled  key(s,g,j) = 32 s + 16 (j>>2) + 4 g + (j&3);  V^T is read with the same relabelling
+//     (two 8-byte loads per fragment), so P never leaves registers and there is no transpose in the loop.
+//     Every product is hi*hi + hi*lo + lo*hi (P is split on the fly), fp32 accumulate.
+//     Output rows are written as 16-byte stores: lane holds O[q][16 dt + 4g .. +3].
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+
+__device__ __forceinline__ uint16_t bf16_bits(float x) {
+    const __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float bf16_val(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+// grid (Tp/64, B*H); block 256.  Each block converts a 64-row time slab of one head.
+__global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ qkv, int T, int Tp, int H, int ld,
+                                                         float scale, uint16_t* __restrict__ planes) {
+    __shared__ float vt[HD][65];
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    const long long plane = (long long)gridDim.y * Tp * HD;
+    uint16_t* Qhi = planes;
+    uint16_t* Qlo = planes + plane;
+    uint16_t* Khi = planes + 2 * plane;
+    uint16_t* Klo = planes + 3 * plane;
+    uint16_t* Vhi = planes + 4 * plane;
+    uint16_t* Vlo = planes + 5 * plane;
+    // 64 rows x 64 dims: thread -> (row r = tid/4 + 64*0, 16 dims)
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    const int t = t0 + r;
+    const float* src = qkv + ((long long)b * T + t) * ld + h * HD + c0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+        if (t < T) {
+            q = *reinterpret_cast<const float4*>(src + i);
+            k = *reinterpret_cast<const float4*>(src + H * HD + i);
+            v = *reinterpret_cast<const float4*>(src + 2 * H * HD + i);
+        }
+        const float qq[4] = {q.x * scale, q.y * scale, q.z * scale, q.w * scale}, kk[4] = {k.x, k.y, k.z, k.w};
+        uint16_t qh[4], ql[4], kh[4], kl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qh[j] = bf16_bits(qq[j]);
+            ql[j] = bf16_bits(qq[j] - bf16_val(qh[j]));
+            kh[j] = bf16_bits(kk[j]);
+            kl[j] = bf16_bits(kk[j] - bf16_val(kh[j]));
+        }
+        const long long o = ((long long)bh * Tp + t) * HD + c0 + i;
+        *reinterpret_cast<uint2*>(Qhi + o) = make_uint2(qh[0] | ((uint32_t)qh[1] << 16), qh[2] | ((uint32_t)qh[3] << 16));
+        *reinterpret_cast<uint2*>(Qlo + o) = make_uint2(ql[0] | ((uint32_t)ql[1] << 16), ql[2] | ((uint32_t)ql[3] << 16));
+        *reinterpret_cast<uint2*>(Khi + o) = make_uint2(kh[0] | ((uint32_t)kh[1] << 16), kh[2] | ((uint32_t)kh[3] << 16));
+        *reinterpret_cast<uint2*>(Klo + o) = make_uint2(kl[0] | ((uint32_t)kl[1] << 16), kl[2] | ((uint32_t)kl[3] << 16));
+        vt[c0 + i + 0][r] = v.x;
+        vt[c0 + i + 1][r] = v.y;
+        vt[c0 + i + 2][r] = v.z;
+        vt[c0 + i + 3][r] = v.w;
+    }
+    __syncthreads();
+    // V^T: thread -> (dim d = tid/4, 16 consecutive times)
+    const int d = tid >> 2, tt0 = (tid & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+        uint16_t vh[4], vl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = vt[d][tt0 + i + j];
+            vh[j] = bf16_bits(x);
+            vl[j] = bf16_bits(x - bf16_val(vh[j]));
+        }
+        const long long o = ((long long)bh * HD + d) * Tp + t0 + tt0 + i;
+        *reinterpret_cast<uint2*>(Vhi + o) = make_uint2(vh[0] | ((uint32_t)vh[1] << 16), vh[2] | ((uint32_t)vh[3] << 16));
+        *reinterpret_cast<uint2*>(Vlo + o) = make_uint2(vl[0] | ((uint32_t)vl[1] << 16), vl[2] | ((uint32_t)vl[3] << 16));
+    }
+}
+
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ bf16x8 ld_frag16(const uint16_t* p) {   // 8 consecutive bf16
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ bf16x8 ld_frag8x2(const uint16_t* p0, const uint16_t* p1) {   // 4 + 4 bf16
+    const u32x2 a = *reinterpret_cast<const u32x2*>(p0), b = *reinterpret_cast<const u32x2*>(p1);
+    const u32x4 v = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// grid (ceil(T/64), B*H); block 256 = 4 independent waves of 16 queries.
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ planes, int T, int Tp, int H,
+                                                         int ldo, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    if (q0 >= T) return;   // wave-uniform; no barriers in this kernel
+    const int fr = lane & 15, g = lane >> 4;
+    const long long plane = (long long)gridDim.y * Tp * HD;
+    const uint16_t* Qhi = planes + (long long)bh * Tp * HD;
+    const uint16_t* Qlo = Qhi + plane;
+    const uint16_t* Khi = Qhi + 2 * plane;
+    const uint16_t* Klo = Qhi + 3 * plane;
+    const uint16_t* Vhi = Qhi + 4 * plane;   // [64][Tp]
+    const uint16_t* Vlo = Qhi + 5 * plane;
+
+    // Q fragments (B operand of S^T): lane (q = fr, g) holds Q[q0+fr][32 ks + 8 g .. +7]
+    bf16x8 qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const long long o = (long long)(q0 + fr) * HD + ks * 32 + g * 8;   // rows up to Tp exist (zero padded)
+        qh[ks] = ld_frag16(Qhi + o);
+        ql[ks] = ld_frag16(Qlo + o);
+    }
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc_o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -1.0e30f, l = 0.f;
+
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        // ---- S^T tile: 4 key tiles x (16 keys x 16 queries)
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const long long o = (long long)(j0 + t * 16 + fr) * HD + ks * 32 + g * 8;
+                const bf16x8 kh = ld_frag16(Khi + o), kl = ld_frag16(Klo + o);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[t], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for query fr (keys 16 t + 4 g + r in this lane)
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (j0 + t * 16 + g * 4 + r >= T) s[t][r] = -1.0e30f;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float corr = __expf(m - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = s[t][r] > -1.0e29f ? __expf(s[t][r] - mn) : 0.f;
+                s[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * corr + sum;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_o[dt] *= corr;
+        // ---- P fragments (B operand): k-step ks covers key tiles 2ks, 2ks+1
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = s[2 * ks + (j >> 2)][j & 3];
+                const __bf16 hi = (__bf16)p;
+                ph[ks][j] = hi;
+                pl[ks][j] = (__bf16)(p - (float)hi);
+            }
+        // ---- O^T += V^T . P^T : A fragment of d-tile dt, k-step ks = V^T[16 dt + fr][j0 + 32 ks + {4g.., 16+4g..}]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const long long o = (long long)(dt * 16 + fr) * Tp + j0 + ks * 32 + g * 4;
+                const bf16x8 vh = ld_frag8x2(Vhi + o, Vhi + o + 16), vl = ld_frag8x2(Vlo + o, Vlo + o + 16);
+                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[ks], acc_o[dt], 0, 0, 0);
+                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[ks], acc_o[dt], 0, 0, 0);
+                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[ks], acc_o[dt], 0, 0, 0);
+            }
+    }
+    if (q0 + fr < T) {
+        const float inv = 1.f / l;
+        float* op = out + ((long long)b * T + q0 + fr) * ldo + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(op + dt * 16) =
+                make_float4(acc_o[dt][0] * inv, acc_o[dt][1] * inv, acc_o[dt][2] * inv, acc_o[dt][3] * inv);
+    }
+}
+
+}  // namespace
+
+// scratch: 6 * B*H*Tp*64 bf16 (= 12 * B*H*Tp*64 bytes), Tp = T rounded up to 64.
+extern "C" int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, float scale, float* out, int ldo,
+                                 uint16_t* scratch, void* stream) {
+    if (!qkv || !out || !scratch || B <= 0 || H <= 0 || T <= 0 || (ld & 3) || (ldo & 3)) return AVI_EINVAL;
+    if (ld < 3 * H * HD || ldo < H * HD || (long long)B * H > 65535) return AVI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+        (reinterpret_cast<uintptr_t>(scratch) & 15))
+        return AVI_EINVAL;
+    const int Tp = (T + 63) / 64 * 64;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(attn_prep_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, qkv, T, Tp, H, ld, scale, scratch);
+    hipLaunchKernelGGL(attn_mfma_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, scratch, T, Tp, H, ldo, out);
+    return avi_launch_status();
+}

@@ -238,8 +238,9 @@ class InstructDiffusionPrior:
             noise[0] = image_embed.reshape(B, DIM).to(self.device, torch.float32)
         te = text_cond["text_embed"].reshape(B, DIM).to(self.device, torch.float32).contiguous()
         out = torch.empty((B, DIM), dtype=torch.float32, device=self.device)
+        temb = torch.empty((T, DIM), dtype=torch.float32, device=self.device)
         import ctypes as C
         L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
-                                          1.0 / self.image_embed_scale, out.data_ptr(), L.stream_ptr()),
-                "avi_prior_sample")
+                                          1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
+                                          L.stream_ptr()), "avi_prior_sample")
         return out.view(*shape)

@@ -111,8 +111,7 @@ class Wav2Vec2Model:
         d = HIDDEN // HEADS
         for ly in self.layers:
             qkv = ops.linear(h, ly.qkv, prec=self.prec)                               # (B,T,2304)
-            q, k, v = qkv[..., :HIDDEN], qkv[..., HIDDEN:2 * HIDDEN], qkv[..., 2 * HIDDEN:]
-            att = ops.attention(q, k, v, HEADS, d, 3 * HIDDEN, 3 * HIDDEN, T, T, B, d ** -0.5)
+            att = ops.attention_d64(qkv, HEADS, d ** -0.5)                           # MFMA, bf16x3 operands
             h = ops.linear(att, ly.out, residual=h, prec=self.prec)
             h = ops.layernorm(h, *ly.ln1, out=h)
             f = ops.linear(h, ly.ff1, act=ops.ACT_GELU, prec=self.prec)

@@ -68,8 +68,9 @@ SIGNATURES = {
     "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+    "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp],
+    "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -201,3 +201,18 @@ def attention(q, k, v, H, D, ldq, ldk, Tq, Tk, B, scale, bias_mode=0, slopes=Non
                                    ldk, H * D, scale, bias_mode, L.ptr(slopes), period, L.stream_ptr()),
             "avi_attention")
     return out
+
+
+def attention_d64(qkv, H, scale, out=None):
+    """Unbiased head-dim-64 attention over a packed (B, T, 3*H*64) projection on the matrix cores."""
+    qkv = _f32c(qkv, "qkv")
+    B, T, ld = qkv.shape
+    if ld != 3 * H * 64:
+        raise ValueError(f"attention_d64: last dim {ld} != 3*H*64")
+    if out is None:
+        out = torch.empty((B, T, H * 64), dtype=torch.float32, device=qkv.device)
+    Tp = (T + 63) // 64 * 64
+    scratch = torch.empty((6 * B * H * Tp * 64,), dtype=torch.int16, device=qkv.device)
+    L.check(L.load().avi_attention_d64(qkv.data_ptr(), B, H, T, ld, scale, out.data_ptr(), H * 64, scratch.data_ptr(),
+                                       L.stream_ptr()), "avi_attention_d64")
+    return out

@@ -123,6 +123,12 @@ int avi_attention(const float* q, const float* k, const float* v, float* out, in
                   int D, int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes,
                   int period, void* stream);
 
+/* Head-dim-64 unbiased attention on the matrix cores (bf16 3-term split, fp32 accumulate): the wav2vec2 encoder
+ * layers.  qkv packed [B][T][ld] (q | k | v, each H*64 wide, ld >= 3*H*64), out [B][T][ldo].
+ * scratch >= 6 * B*H*Tp*64 bf16 values (Tp = T rounded up to 64), 16-byte aligned. */
+int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, float scale, float* out, int ldo,
+                      uint16_t* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Diffusion prior.  Replaces VersatileDiffusionPriorNetwork.forward (models/diffusion_prior.py:223-313),
  * FlaggedCausalTransformer.forward (:154-166) with the dalle2 Attention/FeedForward/LayerNorm blocks,
@@ -163,9 +169,10 @@ int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, 
                       const unsigned char* brain_keep, const unsigned char* image_keep, int B, float* pred,
                       void* stream);
 /* Whole DDPM loop in ONE launch (one workgroup per sample): noise [timesteps+1][B][128], noise[0] = x_T,
- * noise[1+k] = z of the k-th step; out [B][128] = x_0 * inv_scale (inv_scale = 1/sqrt(128)). */
+ * noise[1+k] = z of the k-th step; out [B][128] = x_0 * inv_scale (inv_scale = 1/sqrt(128)).
+ * temb_scratch >= timesteps*128 floats (time embeddings of all timesteps, filled by a first tiny launch). */
 int avi_prior_sample(const AviPriorWeights* w, const float* text_embed, const float* noise, int B,
-                     float inv_scale, float* out, void* stream);
+                     float inv_scale, float* out, float* temb_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FaceFormer-style autoregressive decoder.  Replaces the loop of Faceformer.predict

@@ -59,7 +59,7 @@ def test_bad_arguments_are_rejected_before_launch(lib):
     assert so.avi_attention(None, None, None, None, 1, 1, 1, 1, 64, 64, 64, 64, 1.0, 0, None, 1, None) == -1
     assert so.avi_layernorm(None, 1, 64, None, None, 1e-5, None, None) == -1
     w = lib.AviPriorWeights()
-    assert so.avi_prior_sample(C.byref(w), None, None, 1, 1.0, None, None) == -1
+    assert so.avi_prior_sample(C.byref(w), None, None, 1, 1.0, None, None, None) == -1
 
 
 def test_weight_key_names_and_shapes():

@@ -1,0 +1,36 @@
+"""GPU: long-form utterance (BASELINE config 5: 60 s, T = 1500 frames).  The reference has no behaviour here for
+its mask-limited modules (EMOTE mask 1200 frames, FaceFormer 600: SURVEY.md section 5), but the audio encoder and the
+mask-free EMOTE/FLINT head (alibi is computed analytically here) are well defined: compare with the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_60s_utterance_matches_oracle(gpu):
+    from avi_talking_amd.weights import make_emote_weights, make_wav2vec2_weights
+    from avi_talking_amd.host.talking_head import TalkingHeadWrapper
+    from oracle import emote as OE, wav2vec2 as OW
+    wa, wh = make_wav2vec2_weights(0), make_emote_weights(1)
+    T = 1500
+    g = torch.Generator().manual_seed(61)
+    pcm = (torch.randn(1, T * 640, generator=g) * 3000).to(torch.int16)
+    style = torch.randn(1, 1, 128, generator=g) * 0.5
+    th = TalkingHeadWrapper(wa, wh, device=gpu)
+    out = th({"raw_audio": pcm.view(1, T, 640), "samplerate": [16000]}, style_emb=style.to(gpu),
+             is_external_style_emb=True)
+    feat = OW.forward(wa, OW.normalize_audio(pcm, joint=True), frame_num=T)
+    ref = OE.forward(wh, feat, style)
+    e = max((out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
+            (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
+    print(f"T=1500 coefficient err {e:.2e}")
+    assert out["predicted_exp"].shape == (1, T, 50)
+    assert e < 1e-3
+
+
+def test_faceformer_rejects_sequences_beyond_reference_tables(gpu):
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    ff = Faceformer(make_faceformer_weights(2, feature_dim=64), device=gpu)
+    with pytest.raises(ValueError):
+        ff.decode(torch.zeros(1, 601, 64, device=gpu))

@@ -153,3 +153,16 @@ def test_pad_repeat_and_pack(gpu):
     assert torch.equal(xg, ref)
     a = _rand((2, 8), 23)
     assert torch.allclose(ops.add_rowbcast(x.to(gpu), a.to(gpu)).cpu(), x + a[:, None])
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 12, 250), (1, 3, 64), (2, 2, 65), (1, 1, 17), (1, 4, 499)])
+def test_attention_d64_mfma(gpu, B, H, T):
+    from avi_talking_amd import ops
+    D = 64
+    qkv = _rand((B, T, 3 * H * D), 30) * 1.5
+    q, k, v = [t.reshape(B, T, H, D).transpose(1, 2).double() for t in qkv.split(H * D, -1)]
+    ref = torch.matmul(torch.softmax(torch.matmul(q, k.transpose(2, 3)) * D ** -0.5, -1), v)
+    ref = ref.transpose(1, 2).reshape(B, T, H * D)
+    out = ops.attention_d64(qkv.to(gpu), H, D ** -0.5).cpu().double()
+    err = (out - ref).abs().max().item()
+    assert err < 1e-4, err          # values up to ~6 in magnitude: ~1e-5 relative
