@@ -26,6 +26,12 @@ namespace {
 constexpr int DIM = 128, NTOK = 3, HEADS = 8, DH = 64, INNER = HEADS * DH, FFI = 512, ROT = 32;
 constexpr int NQKV = INNER + 2 * DH;   // 640
 constexpr int NT = 512;
+#ifndef PRIOR_UB
+#define PRIOR_UB 16
+#endif
+#ifndef PRIOR_WAVES_PER_SIMD
+#define PRIOR_WAVES_PER_SIMD 2
+#endif
 constexpr int PART = 6144;             // max KS*3*N over the four linears
 
 struct Smem {
@@ -56,7 +62,7 @@ __device__ __forceinline__ void linear3_partial(const float* __restrict__ Wt, co
     const int k0 = ks * KC;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
     const float4* wp = reinterpret_cast<const float4*>(Wt) + cq;
-    constexpr int UB = KC < 16 ? KC : 16;      // 16-B loads kept in flight per thread (32 spills at 256 VGPRs)
+    constexpr int UB = KC < PRIOR_UB ? KC : PRIOR_UB;   // 16-B loads kept in flight per thread
 #pragma unroll 1   // keep ONE batch of UB loads live: hipcc otherwise unrolls this loop and spills the batches
     for (int kb = 0; kb < KC; kb += UB) {
         float4 w[UB];
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(NT) void prior_time_table_kernel(const AviPriorWeig
 
 // mode 0: one forward at per-sample timestep t[b] with optional cond-drop masks -> pred[b]
 // mode 1: full DDPM loop t = T-1..0 with noise[0] = x_T, noise[1+k] = z of the k-th step -> out[b] = x_0 * inv_scale
-__global__ __launch_bounds__(NT) void prior_kernel(const AviPriorWeights w_arg, const float* __restrict__ text_embed,
+__global__ __launch_bounds__(NT, PRIOR_WAVES_PER_SIMD) void prior_kernel(const AviPriorWeights w_arg, const float* __restrict__ text_embed,
                                                     const float* __restrict__ x_in, const int* __restrict__ t_in,
                                                     const unsigned char* __restrict__ brain_keep,
                                                     const unsigned char* __restrict__ image_keep,
@@ -337,6 +343,14 @@ void set_attr() {
 }
 
 }  // namespace
+
+// shared with prior_mfma.hip
+int avi_prior_time_table_launch(const AviPriorWeights* w, float* temb, hipStream_t s) {
+    if (check_weights(w) != AVI_OK || !temb) return AVI_EINVAL;
+    set_attr();
+    hipLaunchKernelGGL(prior_time_table_kernel, dim3(w->timesteps), dim3(NT), sizeof(Smem), s, *w, temb);
+    return avi_launch_status();
+}
 
 extern "C" int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, const float* text_embed,
                                  const unsigned char* brain_keep, const unsigned char* image_keep, int B,

@@ -156,6 +156,27 @@ class VersatileDiffusionPriorNetwork:
             ly.w2 = T(f + "5.weight")
         cw.final_g = dev(w[c + "norm.g"])
         cw.wproj = T(c + "project_out.weight")
+        # bf16 hi/lo planes ([N][K], torch layout) of the streamed matrices for the batched matrix-core sampler
+        pl = L.AviPriorPlanes()
+        self._packs = []
+
+        def planes(mat):
+            pw = ops.PackedWeight(mat.to(self.device))                 # [N][K] bf16 hi / lo
+            N, K = mat.shape
+            frag = lambda t: (t[:N].view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous())
+            hi, lo = frag(pw.hi), frag(pw.lo)                          # [N/16][K/32][g][c][8] = lane (c + 16 g)
+            self._packs += [hi, lo]
+            return hi.data_ptr(), lo.data_ptr()
+
+        for l in range(depth):
+            a, f = f"{c}layers.{l}.0.", f"{c}layers.{l}.1."
+            lp = pl.layer[l]
+            lp.qkv_hi, lp.qkv_lo = planes(torch.cat([w[a + "to_q.weight"], w[a + "to_kv.weight"]], 0))
+            lp.out_hi, lp.out_lo = planes(w[a + "to_out.0.weight"])
+            lp.w1_hi, lp.w1_lo = planes(w[f + "1.weight"])
+            lp.w2_hi, lp.w2_lo = planes(w[f + "5.weight"])
+        pl.proj_hi, pl.proj_lo = planes(w[c + "project_out.weight"])
+        self.planes = pl
         cw.coef1 = dev(sched["posterior_mean_coef1"])
         cw.coef2 = dev(sched["posterior_mean_coef2"])
         cw.logvar = dev(sched["posterior_log_variance_clipped"])
@@ -205,6 +226,10 @@ class InstructDiffusionPrior:
         self.noise_scheduler = SimpleNamespace(num_timesteps=timesteps, **net.sched)
         self.text_cond_drop_prob = self.image_cond_drop_prob = cond_drop_prob
         self.predict_x_start = True
+        # samples per workgroup of the sampler: 0 = one workgroup per sample on the fp32 vector pipe (prior.hip),
+        # 1..5 = matrix-core kernel (prior_mfma.hip).  AVI_PRIOR_SPG overrides (tuning knob).
+        import os
+        self.samples_per_group = int(os.environ.get("AVI_PRIOR_SPG", "1"))
 
     @classmethod
     def from_state_dict(cls, state_dict, device="cuda", prec=ops.PREC_BF16X3, timesteps=100):
@@ -220,7 +245,7 @@ class InstructDiffusionPrior:
 
     @torch.no_grad()
     def p_sample_loop(self, shape, text_cond, cond_scale=1.0, timesteps=None, generator=None, image_embed=None,
-                      noise=None):
+                      noise=None, samples_per_group=None):
         """dalle2 ``DiffusionPrior.p_sample_loop`` -> ``p_sample_loop_ddpm`` (models/diffusion_prior.py:343-367).
         Returns the sampled embedding divided by ``image_embed_scale``, shape ``shape``.
         ``noise`` (T+1,B,1,128) may be injected for reproducibility across devices."""
@@ -240,7 +265,15 @@ class InstructDiffusionPrior:
         out = torch.empty((B, DIM), dtype=torch.float32, device=self.device)
         temb = torch.empty((T, DIM), dtype=torch.float32, device=self.device)
         import ctypes as C
-        L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
-                                          1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
-                                          L.stream_ptr()), "avi_prior_sample")
+        spg = self.samples_per_group if samples_per_group is None else samples_per_group
+        if spg <= 0:     # one workgroup per sample, fp32 vector pipe (prior.hip)
+            L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
+                                              1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
+                                              L.stream_ptr()), "avi_prior_sample")
+        else:            # up to 5 samples per workgroup on the matrix cores (prior_mfma.hip)
+            spg = min(spg, B)
+            L.check(L.load().avi_prior_sample_batched(C.byref(self.net.cw), C.byref(self.net.planes), te.data_ptr(),
+                                                      noise.data_ptr(), B, spg, 1.0 / self.image_embed_scale,
+                                                      out.data_ptr(), temb.data_ptr(), L.stream_ptr()),
+                    "avi_prior_sample_batched")
         return out.view(*shape)

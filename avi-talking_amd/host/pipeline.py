@@ -23,7 +23,9 @@ class SamplingPipeline:
         self.device = torch.device(device)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
         self.prior = InstructDiffusionPrior.from_state_dict(prior_sd, device=device, prec=prec)
-        self.side = torch.cuda.Stream(device=self.device)
+        # high priority: the prior branch is the longer one and its small aligner GEMMs must not queue behind the
+        # chip-filling conv GEMMs of the audio branch
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
         self._graph = None
         self._static = None
 

@@ -47,6 +47,14 @@ class AviPriorWeights(C.Structure):
                 [(n, _vp) for n in ("final_g", "wproj", "coef1", "coef2", "logvar")])
 
 
+class AviPriorLayerPlanes(C.Structure):
+    _fields_ = [(n, _vp) for n in ("qkv_hi", "qkv_lo", "out_hi", "out_lo", "w1_hi", "w1_lo", "w2_hi", "w2_lo")]
+
+
+class AviPriorPlanes(C.Structure):
+    _fields_ = [("layer", AviPriorLayerPlanes * PRIOR_MAX_DEPTH), ("proj_hi", _vp), ("proj_lo", _vp)]
+
+
 class AviFaceformerWeights(C.Structure):
     _fields_ = ([("D", _i), ("V", _i), ("period", _i)] +
                 [(n, _vp) for n in ("wqkv", "bqkv", "wo", "bo", "n1g", "n1b", "n2g", "n2b", "n3g", "n3b", "w1", "b1",
@@ -71,6 +79,7 @@ SIGNATURES = {
     "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
+    "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

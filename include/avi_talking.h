@@ -163,6 +163,20 @@ typedef struct AviPriorWeights {
     const float *coef1, *coef2, *logvar;     /* [timesteps] posterior_mean_coef1/2, posterior_log_variance_clipped */
 } AviPriorWeights;
 
+/* bf16 hi/lo planes of the streamed denoiser matrices for the batched matrix-core sampler, FRAGMENT-MAJOR:
+ * plane[((n/16)*(K/32) + k/32)*512 + ((n%16) + 16*((k%32)/8))*8 + k%8] = W[n][k]  (W in torch layout [N][K]),
+ * i.e. [N/16][K/32][64 lanes][8]: one MFMA fragment load of a wave is one contiguous 1-KiB read. */
+typedef struct AviPriorLayerPlanes {
+    const uint16_t *qkv_hi, *qkv_lo;   /* [640][128]  cat(to_q.weight, to_kv.weight) */
+    const uint16_t *out_hi, *out_lo;   /* [128][512]  to_out.0.weight */
+    const uint16_t *w1_hi, *w1_lo;     /* [1024][128] layers.{l}.1.1.weight */
+    const uint16_t *w2_hi, *w2_lo;     /* [128][512]  layers.{l}.1.5.weight */
+} AviPriorLayerPlanes;
+typedef struct AviPriorPlanes {
+    AviPriorLayerPlanes layer[AVI_PRIOR_MAX_DEPTH];
+    const uint16_t *proj_hi, *proj_lo; /* [128][128]  project_out.weight */
+} AviPriorPlanes;
+
 /* One denoiser evaluation per sample (training forward / unit of the sampler):
  * x_t [B][128], t [B] int32, text_embed [B][128], keep masks [B] bytes or NULL (= keep) -> pred [B][128]. */
 int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, const float* text_embed,
@@ -173,6 +187,12 @@ int avi_prior_forward(const AviPriorWeights* w, const float* x_t, const int* t, 
  * temb_scratch >= timesteps*128 floats (time embeddings of all timesteps, filled by a first tiny launch). */
 int avi_prior_sample(const AviPriorWeights* w, const float* text_embed, const float* noise, int B,
                      float inv_scale, float* out, float* temb_scratch, void* stream);
+/* Same loop with `samples_per_group` (1..5) samples per workgroup on the matrix cores (bf16 3-term split): the
+ * weights are streamed once per step per GROUP instead of per sample.  Small vectors (gains, null kv, biases,
+ * schedule) come from `w`, the streamed matrices from `p`. */
+int avi_prior_sample_batched(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
+                             const float* noise, int B, int samples_per_group, float inv_scale, float* out,
+                             float* temb_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FaceFormer-style autoregressive decoder.  Replaces the loop of Faceformer.predict
