@@ -6,7 +6,7 @@
 //                          Q  [B*H][Tp][64]  (pre-multiplied by the softmax scale)
 //                          K  [B*H][Tp][64]
 //                          V^T[B*H][64][Tp]  (transposed through LDS), Tp = T rounded up to 64, zero padded.
-//  2. attn_mfma_kernel   one wave = 16 queries, flash-style loop over 64-key tiles, no LDS and no barriers:
+//  2. attn_mfma_kernel   one wave = 16 (or 2 x 16) queries, flash-style loop over 64-key tiles, no LDS and no barriers:
 //        S^T = K . Q^T      (A = K rows, B = Q cols)   -> lane (q = l&15, g = l>>4) holds keys 16t + 4g + r
 //        online softmax per query (16 own values + 2 xor-shuffles across the 4 lane groups)
 //        O^T = V^T . P^T    (A = V^T rows d, B = P from the accumulator registers)
@@ -99,12 +99,14 @@ __device__ __forceinline__ bf16x8 ld_frag8x2(const uint16_t* p0, const uint16_t*
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// grid (ceil(T/64), B*H); block 256 = 4 independent waves of 16 queries.
+// grid (ceil(T/(64 QT)), B*H); block 256 = 4 independent waves of QT x 16 queries.  Every K / V^T fragment a wave
+// loads feeds QT query tiles, which halves (QT = 2) the L1 traffic per MFMA of this LDS-free design.
+template <int QT>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restrict__ planes, int T, int Tp, int H,
                                                          int ldo, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QT);
     if (q0 >= T) return;   // wave-uniform; no barriers in this kernel
     const int fr = lane & 15, g = lane >> 4;
     const long long plane = (long long)gridDim.y * Tp * HD;
@@ -115,73 +117,88 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
     const uint16_t* Vhi = Qhi + 4 * plane;   // [64][Tp]
     const uint16_t* Vlo = Qhi + 5 * plane;
 
-    // Q fragments (B operand of S^T): lane (q = fr, g) holds Q[q0+fr][32 ks + 8 g .. +7]
-    bf16x8 qh[2], ql[2];
+    // Q fragments (B operand of S^T): lane (q = fr, g) holds Q[q0 + 16 qt + fr][32 ks + 8 g .. +7]
+    // (rows up to Tp exist, zero padded; q0 + 16 QT <= Tp because Tp is a multiple of 64)
+    bf16x8 qh[QT][2], ql[QT][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const long long o = (long long)(q0 + fr) * HD + ks * 32 + g * 8;   // rows up to Tp exist (zero padded)
-        qh[ks] = ld_frag16(Qhi + o);
-        ql[ks] = ld_frag16(Qlo + o);
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const long long o = (long long)(q0 + qt * 16 + fr) * HD + ks * 32 + g * 8;
+            qh[qt][ks] = ld_frag16(Qhi + o);
+            ql[qt][ks] = ld_frag16(Qlo + o);
+        }
+    f32x4 acc_o[QT][4];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[qt] = -1.0e30f;
+        l[qt] = 0.f;
     }
-    f32x4 acc_o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc_o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -1.0e30f, l = 0.f;
 
     for (int j0 = 0; j0 < T; j0 += 64) {
-        // ---- S^T tile: 4 key tiles x (16 keys x 16 queries)
-        f32x4 s[4];
+        // ---- S^T tile: 4 key tiles x (16 keys x 16 queries) per query tile
+        f32x4 s[QT][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const long long o = (long long)(j0 + t * 16 + fr) * HD + ks * 32 + g * 8;
                 const bf16x8 kh = ld_frag16(Khi + o), kl = ld_frag16(Klo + o);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[t], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[qt][ks], s[qt][t], 0, 0, 0);
+                    s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[qt][ks], s[qt][t], 0, 0, 0);
+                    s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[qt][ks], s[qt][t], 0, 0, 0);
+                }
             }
         }
-        // ---- online softmax for query fr (keys 16 t + 4 g + r in this lane)
-        float mx = -1.0e30f;
+        // ---- online softmax for query fr of each tile (keys 16 t + 4 g + r in this lane)
+        bf16x8 ph[QT][2], pl[QT][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -1.0e30f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (j0 + t * 16 + g * 4 + r >= T) s[t][r] = -1.0e30f;
-                mx = fmaxf(mx, s[t][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float corr = __expf(m - mn);
-        float sum = 0.f;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+                for (int r = 0; r < 4; ++r) {
+                    if (j0 + t * 16 + g * 4 + r >= T) s[qt][t][r] = -1.0e30f;
+                    mx = fmaxf(mx, s[qt][t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[qt], mx);
+            const float corr = __expf(m[qt] - mn);
+            float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = s[t][r] > -1.0e29f ? __expf(s[t][r] - mn) : 0.f;
-                s[t][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        l = l * corr + sum;
-        m = mn;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc_o[dt] *= corr;
-        // ---- P fragments (B operand): k-step ks covers key tiles 2ks, 2ks+1
-        bf16x8 ph[2], pl[2];
+                for (int r = 0; r < 4; ++r) {
+                    const float p = s[qt][t][r] > -1.0e29f ? __expf(s[qt][t][r] - mn) : 0.f;
+                    s[qt][t][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l[qt] = l[qt] * corr + sum;
+            m[qt] = mn;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] *= corr;
+            // P fragments (B operand): k-step ks covers key tiles 2ks, 2ks+1
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = s[2 * ks + (j >> 2)][j & 3];
-                const __bf16 hi = (__bf16)p;
-                ph[ks][j] = hi;
-                pl[ks][j] = (__bf16)(p - (float)hi);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = s[qt][2 * ks + (j >> 2)][j & 3];
+                    const __bf16 hi = (__bf16)p;
+                    ph[qt][ks][j] = hi;
+                    pl[qt][ks][j] = (__bf16)(p - (float)hi);
+                }
+        }
         // ---- O^T += V^T . P^T : A fragment of d-tile dt, k-step ks = V^T[16 dt + fr][j0 + 32 ks + {4g.., 16+4g..}]
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -189,19 +206,24 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
             for (int ks = 0; ks < 2; ++ks) {
                 const long long o = (long long)(dt * 16 + fr) * Tp + j0 + ks * 32 + g * 4;
                 const bf16x8 vh = ld_frag8x2(Vhi + o, Vhi + o + 16), vl = ld_frag8x2(Vlo + o, Vlo + o + 16);
-                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[ks], acc_o[dt], 0, 0, 0);
-                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[ks], acc_o[dt], 0, 0, 0);
-                acc_o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[ks], acc_o[dt], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                    acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                }
             }
     }
-    if (q0 + fr < T) {
-        const float inv = 1.f / l;
-        float* op = out + ((long long)b * T + q0 + fr) * ldo + h * HD + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<float4*>(op + dt * 16) =
-                make_float4(acc_o[dt][0] * inv, acc_o[dt][1] * inv, acc_o[dt][2] * inv, acc_o[dt][3] * inv);
-    }
+    for (int qt = 0; qt < QT; ++qt)
+        if (q0 + qt * 16 + fr < T) {
+            const float inv = 1.f / l[qt];
+            float* op = out + ((long long)b * T + q0 + qt * 16 + fr) * ldo + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(op + dt * 16) = make_float4(
+                    acc_o[qt][dt][0] * inv, acc_o[qt][dt][1] * inv, acc_o[qt][dt][2] * inv, acc_o[qt][dt][3] * inv);
+        }
 }
 
 }  // namespace
@@ -217,6 +239,10 @@ extern "C" int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, 
     const int Tp = (T + 63) / 64 * 64;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(attn_prep_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, qkv, T, Tp, H, ld, scale, scratch);
-    hipLaunchKernelGGL(attn_mfma_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, scratch, T, Tp, H, ldo, out);
+    // two query tiles per wave once there are enough waves to fill the 1024 SIMDs, else one
+    if ((long long)B * H * ((T + 31) / 32) >= 2048)
+        hipLaunchKernelGGL(attn_mfma_kernel<2>, dim3((T + 127) / 128, B * H), dim3(256), 0, s, scratch, T, Tp, H, ldo, out);
+    else
+        hipLaunchKernelGGL(attn_mfma_kernel<1>, dim3(Tp / 64, B * H), dim3(256), 0, s, scratch, T, Tp, H, ldo, out);
     return avi_launch_status();
 }

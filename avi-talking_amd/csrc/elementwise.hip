@@ -4,6 +4,26 @@
 
 namespace {
 
+// split-plane helpers: x = hi + lo (two bf16), 4 values at a time
+__device__ __forceinline__ void split4_store(uint16_t* hi, uint16_t* lo, long long o, const float v[4]) {
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)v[j];
+        const __bf16 lb = (__bf16)(v[j] - (float)hb);
+        h[j] = __builtin_bit_cast(uint16_t, hb);
+        l[j] = __builtin_bit_cast(uint16_t, lb);
+    }
+    *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+    *reinterpret_cast<uint2*>(lo + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+}
+__device__ __forceinline__ float4 join4_load(const uint16_t* hi, const uint16_t* lo, long long o) {
+    const uint2 h = *reinterpret_cast<const uint2*>(hi + o), l = *reinterpret_cast<const uint2*>(lo + o);
+    auto f = [](uint32_t b) { return __builtin_bit_cast(float, b); };
+    return make_float4(f(h.x << 16) + f(l.x << 16), f(h.x & 0xffff0000u) + f(l.x & 0xffff0000u),
+                       f(h.y << 16) + f(l.y << 16), f(h.y & 0xffff0000u) + f(l.y & 0xffff0000u));
+}
+
 // ------------------------------------------------------------------ audio zero-mean / unit-var
 // stats[2*s + {0,1}] = sum, sum of squares (double) of clip s (s = 0 when joint).
 template <bool I16>
@@ -116,7 +136,8 @@ __global__ void conv0_finalize_kernel(const double* __restrict__ mom, const floa
 constexpr int C0_TT = 64;
 __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ x, int N, int T0,
                                                            const float* __restrict__ w0,
-                                                           const float* __restrict__ ss, float* __restrict__ y) {
+                                                           const float* __restrict__ ss, float* __restrict__ y,
+                                                           uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo) {
     __shared__ float sx[C0_TT * ST0 + K0 + 2];
     const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
     const float* xb = x + (long long)b * N;
@@ -151,7 +172,9 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
             for (int j = 0; j < K0; ++j) a = fmaf(w[q][j], xv[j], a);
             o[q] = avi_gelu(a * sc[q] + sh[q]);
         }
-        *reinterpret_cast<float4*>(y + ((long long)b * T0 + t) * C0 + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        const long long off = ((long long)b * T0 + t) * C0 + cg * 4;
+        if (y) *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        if (y_hi) split4_store(y_hi, y_lo, off, o);
     }
 }
 
@@ -161,7 +184,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int act,
                                                          const float* __restrict__ mask, const float* residual,
-                                                         int stable, float* out) {
+                                                         int stable, float* out, uint16_t* __restrict__ out_hi,
+                                                         uint16_t* __restrict__ out_lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* x = in + (long long)row * C;
@@ -195,7 +219,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
-    float* o = out + (long long)row * C;
+    float* o = out ? out + (long long)row * C : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
@@ -216,7 +240,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
                 const float4 rr = reinterpret_cast<const float4*>(residual + (long long)row * C)[idx];
                 r.x += rr.x; r.y += rr.y; r.z += rr.z; r.w += rr.w;
             }
-            reinterpret_cast<float4*>(o)[idx] = r;
+            if (o) reinterpret_cast<float4*>(o)[idx] = r;
+            if (out_hi) {
+                const float rv[4] = {r.x, r.y, r.z, r.w};
+                split4_store(out_hi, out_lo, (long long)row * C + idx * 4, rv);
+            }
         }
     }
 }
@@ -224,8 +252,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
 // out[b][t] = LN( lerp(in[b][i0], in[b][i1]) ), align_corners=True index math of
 // torch upsample_linear1d: scale = (Tin-1)/(Tout-1), src = scale*t, i0 = (int)src, l1 = src - i0.
 template <int MAXV>
-__global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict__ in, int B, int Tin, int C, int Tout,
-                                                         const float scale, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict__ in, const uint16_t* __restrict__ in_hi,
+                                                         const uint16_t* __restrict__ in_lo, int B, int Tin, int C,
+                                                         int Tout, const float scale, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          float* __restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -240,8 +269,7 @@ __global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict_
     if (i0 > Tin - 1) i0 = Tin - 1;
     const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
     const float l1 = src - (float)i0, l0 = 1.f - l1;
-    const float4* x0 = reinterpret_cast<const float4*>(in + ((long long)b * Tin + i0) * C);
-    const float4* x1 = reinterpret_cast<const float4*>(in + ((long long)b * Tin + i1) * C);
+    const long long o0 = ((long long)b * Tin + i0) * C, o1 = ((long long)b * Tin + i1) * C;
     const int nv = C >> 2;
     float4 v[MAXV];
     float s = 0.f;
@@ -249,7 +277,8 @@ __global__ __launch_bounds__(256) void interp_ln_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            const float4 a = x0[idx], c = x1[idx];
+            const float4 a = in ? *reinterpret_cast<const float4*>(in + o0 + idx * 4) : join4_load(in_hi, in_lo, o0 + idx * 4);
+            const float4 c = in ? *reinterpret_cast<const float4*>(in + o1 + idx * 4) : join4_load(in_hi, in_lo, o1 + idx * 4);
             v[i] = make_float4(l0 * a.x + l1 * c.x, l0 * a.y + l1 * c.y, l0 * a.z + l1 * c.z, l0 * a.w + l1 * c.w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -368,10 +397,10 @@ extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, 
     return avi_launch_status();
 }
 
-extern "C" int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma,
-                                 const float* beta, float eps, float* y, double* moments, float* scale_shift,
-                                 void* stream) {
-    if (!x || !w0 || !gamma || !beta || !y || !moments || !scale_shift || B <= 0 || N < K0) return AVI_EINVAL;
+static int conv0_impl(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta, float eps,
+                      float* y, uint16_t* y_hi, uint16_t* y_lo, double* moments, float* scale_shift, void* stream) {
+    if (!x || !w0 || !gamma || !beta || (!y && !y_hi) || !moments || !scale_shift || B <= 0 || N < K0) return AVI_EINVAL;
+    if ((y_hi == nullptr) != (y_lo == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T0 = (N - K0) / ST0 + 1;
     if (hipMemsetAsync(moments, 0, sizeof(double) * NMOM * B, s) != hipSuccess) return avi_launch_status();
@@ -379,8 +408,20 @@ extern "C" int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, 
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, w0, gamma, beta, T0, eps,
                        scale_shift);
     hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + C0_TT - 1) / C0_TT, B), dim3(256), 0, s, x, N, T0, w0,
-                       scale_shift, y);
+                       scale_shift, y, y_hi, y_lo);
     return avi_launch_status();
+}
+
+extern "C" int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma,
+                                 const float* beta, float eps, float* y, double* moments, float* scale_shift,
+                                 void* stream) {
+    return conv0_impl(x, B, N, w0, gamma, beta, eps, y, nullptr, nullptr, moments, scale_shift, stream);
+}
+
+extern "C" int avi_conv0_gn_gelu_planes(const float* x, int B, int N, const float* w0, const float* gamma,
+                                        const float* beta, float eps, uint16_t* y_hi, uint16_t* y_lo, double* moments,
+                                        float* scale_shift, void* stream) {
+    return conv0_impl(x, B, N, w0, gamma, beta, eps, nullptr, y_hi, y_lo, moments, scale_shift, stream);
 }
 
 extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const float* gamma,
@@ -390,7 +431,18 @@ extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int 
     const int rows = B * Tout;
     const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
     hipLaunchKernelGGL(interp_ln_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
-                       B, Tin, C, Tout, scale, gamma, beta, eps, out);
+                       (const uint16_t*)nullptr, (const uint16_t*)nullptr, B, Tin, C, Tout, scale, gamma, beta, eps, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_interp_layernorm_planes(const uint16_t* in_hi, const uint16_t* in_lo, int B, int Tin, int C, int Tout,
+                                           const float* gamma, const float* beta, float eps, float* out, void* stream) {
+    if (!in_hi || !in_lo || !out || B <= 0 || Tin <= 0 || Tout <= 0 || (C & 3) || C > 1024) return AVI_EINVAL;
+    if ((gamma == nullptr) != (beta == nullptr)) return AVI_EINVAL;
+    const int rows = B * Tout;
+    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+    hipLaunchKernelGGL(interp_ln_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const float*)nullptr, in_hi, in_lo, B, Tin, C, Tout, scale, gamma, beta, eps, out);
     return avi_launch_status();
 }
 
@@ -402,10 +454,19 @@ extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* g
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out);
+                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr);
     else
         hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out);
+                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr);
+    return avi_launch_status();
+}
+
+extern "C" int avi_layernorm_planes(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                                    float* out, uint16_t* out_hi, uint16_t* out_lo, void* stream) {
+    if (!in || !out_hi || !out_lo || rows <= 0 || C <= 0 || (C & 3) || C > 1024) return AVI_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       rows, C, gamma, beta, eps, AVI_ACT_NONE, (const float*)nullptr, (const float*)nullptr, 0, out,
+                       out_hi, out_lo);
     return avi_launch_status();
 }
 

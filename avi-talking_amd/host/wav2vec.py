@@ -9,6 +9,7 @@ Inference only: dropout/SpecAugment/LayerDrop are training-time branches of the 
 (models/lib/wav2vec.py:123-141) and are not taken in ``eval()``.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -35,6 +36,9 @@ class Wav2Vec2Model:
         self.device = torch.device(device)
         self.prec = prec
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
+        # AVI_W2V_PLANES=1: split-plane activations + LDS-DMA GEMM for the conv stack / qkv / ffn1 (ties with the
+        # default fp32-activation path end to end; kept as the base for further GEMM work)
+        self.use_planes = os.environ.get("AVI_W2V_PLANES", "0") == "1"
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -84,10 +88,18 @@ class Wav2Vec2Model:
 
     # ------------------------------------------------------------------ stages
     def feature_extractor(self, input_values):
-        """(B, N) -> channels-last (B, L, 512) (the reference returns (B, 512, L))."""
-        h = ops.conv0_gn_gelu(input_values, self.w0, self.gn_g, self.gn_b)
-        for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
-            h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
+        """(B, N) -> channels-last (B, L, 512) (the reference returns (B, 512, L)).
+        Activations between the conv layers travel as split bf16 planes (x = hi + lo): each producer splits once in
+        its epilogue and the LDS-DMA GEMM consumes the planes without any conversion in its loop."""
+        if not self.use_planes:
+            h = ops.conv0_gn_gelu(input_values, self.w0, self.gn_g, self.gn_b)
+            for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
+                h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
+            return h
+        h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b)
+        n = len(self.convs)
+        for i, (pw, k, s) in enumerate(zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:])):
+            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec, out_planes=i + 1 < n)
         return h
 
     def output_length(self, L50, frame_num=None):
@@ -107,16 +119,29 @@ class Wav2Vec2Model:
                      R=hp.data_ptr(), ldr=HIDDEN, act=ops.ACT_GELU, prec=self.prec, batch=B * POS_G, z_inner=POS_G,
                      sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
                      sR=(T * HIDDEN, cg))
-        h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
+        d = HIDDEN // HEADS
+        if not self.use_planes:
+            h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
+            for ly in self.layers:
+                qkv = ops.linear(h, ly.qkv, prec=self.prec)
+                att = ops.attention_d64(qkv, HEADS, d ** -0.5)
+                h = ops.linear(att, ly.out, residual=h, prec=self.prec)
+                h = ops.layernorm(h, *ly.ln1, out=h)
+                f = ops.linear(h, ly.ff1, act=ops.ACT_GELU, prec=self.prec)
+                h = ops.linear(f, ly.ff2, residual=h, prec=self.prec)
+                h = ops.layernorm(h, *ly.ln2, out=h)
+            return h
+        # LayerNorm outputs feed a big GEMM (qkv / ffn1) AND the residual: emitted as split planes + fp32
+        h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h)
         d = HIDDEN // HEADS
         for ly in self.layers:
-            qkv = ops.linear(h, ly.qkv, prec=self.prec)                               # (B,T,2304)
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=self.prec)                      # (B,T,2304), LDS-DMA GEMM
             att = ops.attention_d64(qkv, HEADS, d ** -0.5)                           # MFMA, bf16x3 operands
             h = ops.linear(att, ly.out, residual=h, prec=self.prec)
-            h = ops.layernorm(h, *ly.ln1, out=h)
-            f = ops.linear(h, ly.ff1, act=ops.ACT_GELU, prec=self.prec)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h)
+            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=self.prec)
             h = ops.linear(f, ly.ff2, residual=h, prec=self.prec)
-            h = ops.layernorm(h, *ly.ln2, out=h)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h)
         return h
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,

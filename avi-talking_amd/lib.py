@@ -29,6 +29,7 @@ class AviGemm(C.Structure):
         ("M", _i), ("N", _i), ("K", _i),
         ("batch", _i), ("z_inner", _i),
         ("act", _i), ("prec", _i),
+        ("Ahi", _vp), ("Alo", _vp), ("Chi", _vp), ("Clo", _vp),
     ]
 
 
@@ -70,6 +71,9 @@ SIGNATURES = {
     "avi_audio_normalize": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "avi_conv0_gn_gelu": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_layernorm_act": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -38,13 +38,15 @@ class PackedWeight:
         return self.hi.numel() * 4
 
 
-def gemm_raw(*, A, lda, Whi, Wlo, C_, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
-             prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0)):
+def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
+             prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0),
+             Ahi=0, Alo=0, Chi=0, Clo=0):
     """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets)."""
     g = L.AviGemm()
-    g.A, g.lda, g.sAo, g.sAi = A, lda, sA[0], sA[1]
+    g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
+    g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
-    g.C, g.ldc, g.sCo, g.sCi = C_, ldc, sC[0], sC[1]
+    g.C, g.ldc, g.sCo, g.sCi = C_ or None, ldc, sC[0], sC[1]
     g.bias, g.sBo, g.sBi = bias or None, sB[0], sB[1]
     g.R, g.ldr, g.sRo, g.sRi = R or None, ldr, sR[0], sR[1]
     g.scale, g.shift = scale or None, shift or None
@@ -215,4 +217,90 @@ def attention_d64(qkv, H, scale, out=None):
     scratch = torch.empty((6 * B * H * Tp * 64,), dtype=torch.int16, device=qkv.device)
     L.check(L.load().avi_attention_d64(qkv.data_ptr(), B, H, T, ld, scale, out.data_ptr(), H * 64, scratch.data_ptr(),
                                        L.stream_ptr()), "avi_attention_d64")
+    return out
+
+
+# ------------------------------------------------------------------ split-plane activations (x = hi + lo, bf16 each)
+class Planes:
+    """An activation stored as two bf16 planes (int16 storage), the operand format of the LDS-DMA GEMM."""
+
+    def __init__(self, shape, device):
+        self.shape = tuple(shape)
+        self.hi = torch.empty(self.shape, dtype=torch.int16, device=device)
+        self.lo = torch.empty(self.shape, dtype=torch.int16, device=device)
+
+    def float(self):
+        return self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
+
+
+def conv0_gn_gelu_planes(x, w0, gamma, beta, eps=1e-5):
+    x = _f32c(x, "x")
+    B, N = x.shape
+    T0 = (N - 10) // 5 + 1
+    out = Planes((B, T0, 512), x.device)
+    mom = torch.empty((65 * B,), dtype=torch.float64, device=x.device)
+    ss = torch.empty((1024 * B,), dtype=torch.float32, device=x.device)
+    L.check(L.load().avi_conv0_gn_gelu_planes(x.data_ptr(), B, N, _f32c(w0, "w0").data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), eps, out.hi.data_ptr(), out.lo.data_ptr(), mom.data_ptr(),
+                                              ss.data_ptr(), L.stream_ptr()), "avi_conv0_gn_gelu_planes")
+    return out
+
+
+def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_planes=True):
+    """Channels-last Conv1d (no padding) on split-plane input: the overlapping-row GEMM on the LDS-DMA kernel."""
+    B, Tin, Cin = xp.shape
+    if pw.K != ksize * Cin or pw.N <= 64:
+        raise ValueError("conv1d_cl_planes: weight does not match the input / N too narrow for the LDS-DMA kernel")
+    Tout = (Tin - ksize) // stride + 1
+    dev = xp.hi.device
+    if out_planes:
+        out = Planes((B, Tout, pw.N), dev)
+        c_args = dict(Chi=out.hi.data_ptr(), Clo=out.lo.data_ptr())
+    else:
+        out = torch.empty((B, Tout, pw.N), dtype=torch.float32, device=dev)
+        c_args = dict(C_=out.data_ptr())
+    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+             ldc=pw.N, M=Tout, N=pw.N, K=pw.K, bias=L.ptr(pw.bias), act=act, prec=prec, batch=B, sA=(Tin * Cin, 0),
+             sC=(Tout * pw.N, 0), **c_args)
+    return out
+
+
+def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None):
+    """fp32 out[..., N] = act(x @ W^T + b) + residual with x given as split planes."""
+    K = xp.shape[-1]
+    if K != pw.K or pw.N <= 64:
+        raise ValueError("linear_planes: shape mismatch / N too narrow for the LDS-DMA kernel")
+    M = 1
+    for d in xp.shape[:-1]:
+        M *= d
+    if out is None:
+        out = torch.empty(xp.shape[:-1] + (pw.N,), dtype=torch.float32, device=xp.hi.device)
+    if residual is not None and _f32c(residual, "residual").numel() != M * pw.N:
+        raise ValueError("linear_planes: bad residual shape")
+    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+             C_=out.data_ptr(), ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act,
+             prec=prec)
+    return out
+
+
+def layernorm_planes(x, gamma, beta, eps=1e-5, out=None, want_f32=True):
+    """LayerNorm emitting the result as fp32 (optional) and as split planes for the next GEMM."""
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if want_f32 and out is None:
+        out = torch.empty_like(x)
+    pl = Planes(x.shape, x.device)
+    L.check(L.load().avi_layernorm_planes(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps,
+                                          out.data_ptr() if want_f32 else None, pl.hi.data_ptr(), pl.lo.data_ptr(),
+                                          L.stream_ptr()), "avi_layernorm_planes")
+    return (out if want_f32 else None), pl
+
+
+def interp_layernorm_planes(xp, Tout, gamma=None, beta=None, eps=1e-5):
+    B, Tin, Cc = xp.shape
+    out = torch.empty((B, Tout, Cc), dtype=torch.float32, device=xp.hi.device)
+    L.check(L.load().avi_interp_layernorm_planes(xp.hi.data_ptr(), xp.lo.data_ptr(), B, Tin, Cc, Tout, L.ptr(gamma),
+                                                 L.ptr(beta), eps, out.data_ptr(), L.stream_ptr()),
+            "avi_interp_layernorm_planes")
     return out

@@ -65,6 +65,13 @@ typedef struct AviGemm {
     int M, N, K;          /* K % 64 == 0 */
     int batch, z_inner;   /* batch >= 1, z_inner >= 1, batch % z_inner == 0 */
     int act, prec;
+    /* Optional "split-plane" activations: a value x is stored as two bf16 planes, x = hi + lo to 2^-17 relative
+     * (same 4 bytes per element as fp32).  When Ahi/Alo are set, A is ignored and the activation tile goes
+     * global -> LDS by LDS-DMA with no conversion in the GEMM loop (gemm_dma.hip; lda and the A batch strides then
+     * count bf16 elements of ONE plane, lda % 8 == 0).  When Chi/Clo are set the epilogue also emits the result as
+     * planes with row stride ldc (C may then be NULL), so chains of GEMMs never pass through fp32. */
+    const uint16_t *Ahi, *Alo;
+    uint16_t *Chi, *Clo;
 } AviGemm;
 int avi_gemm(const AviGemm* g, void* stream);
 
@@ -84,16 +91,26 @@ int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, int joint, 
  * w0 [512][10], gamma/beta [512]; moments: scratch >= 65*B doubles; scale_shift: scratch >= 1024*B floats. */
 int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
                       float eps, float* y, double* moments, float* scale_shift, void* stream);
+/* same, result as bf16 hi/lo planes [B][T0][512] (the A operand format of the LDS-DMA GEMM) */
+int avi_conv0_gn_gelu_planes(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
+                             float eps, uint16_t* y_hi, uint16_t* y_lo, double* moments, float* scale_shift,
+                             void* stream);
 
 /* 50->25 Hz resample (F.interpolate linear, align_corners=True; models/lib/wav2vec.py:67-73) fused
  * with LayerNorm(C) of the feature projection (HF Wav2Vec2FeatureProjection).
  * in [B][Tin][C] -> out [B][Tout][C]; gamma/beta may be NULL (interpolation only). */
 int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const float* gamma,
                          const float* beta, float eps, float* out, void* stream);
+/* same with the input given as bf16 hi/lo planes (x = hi + lo) */
+int avi_interp_layernorm_planes(const uint16_t* in_hi, const uint16_t* in_lo, int B, int Tin, int C, int Tout,
+                                const float* gamma, const float* beta, float eps, float* out, void* stream);
 
 /* row LayerNorm: out[r] = LN(in[r]) * gamma + beta, rows x C.  in == out allowed. */
 int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
                   float* out, void* stream);
+/* LayerNorm whose result is written as fp32 (out, may be NULL) and as bf16 hi/lo planes (the next GEMM's operand) */
+int avi_layernorm_planes(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
+                         float* out, uint16_t* out_hi, uint16_t* out_lo, void* stream);
 /* out[r] = act(LN(in[r])) + residual[r]  (BrainNetwork blocks: Linear -> LayerNorm -> GELU -> +residual,
  * models/diffusion_prior.py:64-76,106-110).  residual may be NULL; in == out allowed. */
 int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,

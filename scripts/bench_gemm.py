@@ -23,10 +23,18 @@ for name, batch, M, N, K, lda in shapes:
     W = torch.randn(N, K, device=dev) * K ** -0.5
     pw = ops.PackedWeight(W)
     C = torch.empty(batch, M, N, device=dev)
-    for prec in ((3, 1, 3 | 0x100, 3 | 0x200, 1 | 0x100, 1 | 0x200) if os.environ.get('GEMM_DIAG') else (3, 1)):
+    for prec in ((3, 1, 3 | 0x100, 3 | 0x200, 1 | 0x100, 1 | 0x200) if os.environ.get("GEMM_DIAG") else (3, 1)):
         def run():
             ops.gemm_raw(A=A.data_ptr(), lda=lda, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=C.data_ptr(), ldc=N,
                          M=M, N=N, K=K, act=ops.ACT_GELU, prec=prec, batch=batch, sA=(rows, 0), sC=(M * N, 0))
+        if os.environ.get("GEMM_PLANES"):
+            hi = A.to(torch.bfloat16); lo = (A - hi.float()).to(torch.bfloat16)
+            Ah, Al = hi.view(torch.int16), lo.view(torch.int16)
+            Ch = torch.empty(batch, M, N, dtype=torch.int16, device=dev); Cl = torch.empty_like(Ch)
+            def run():
+                ops.gemm_raw(Ahi=Ah.data_ptr(), Alo=Al.data_ptr(), lda=lda, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+                             Chi=Ch.data_ptr(), Clo=Cl.data_ptr(), ldc=N, M=M, N=N, K=K, act=ops.ACT_GELU, prec=prec,
+                             batch=batch, sA=(rows, 0), sC=(M * N, 0))
         for _ in range(3): run()
         torch.cuda.synchronize(); t = time.time()
         for _ in range(reps): run()

@@ -155,7 +155,8 @@ def test_pad_repeat_and_pack(gpu):
     assert torch.allclose(ops.add_rowbcast(x.to(gpu), a.to(gpu)).cpu(), x + a[:, None])
 
 
-@pytest.mark.parametrize("B,H,T", [(2, 12, 250), (1, 3, 64), (2, 2, 65), (1, 1, 17), (1, 4, 499)])
+@pytest.mark.parametrize("B,H,T", [(2, 12, 250), (1, 3, 64), (2, 2, 65), (1, 1, 17), (1, 4, 499),
+                                   (32, 12, 250), (16, 12, 1011)])   # the last two take the 2-query-tile kernel
 def test_attention_d64_mfma(gpu, B, H, T):
     from avi_talking_amd import ops
     D = 64
@@ -166,3 +167,44 @@ def test_attention_d64_mfma(gpu, B, H, T):
     out = ops.attention_d64(qkv.to(gpu), H, D ** -0.5).cpu().double()
     err = (out - ref).abs().max().item()
     assert err < 1e-4, err          # values up to ~6 in magnitude: ~1e-5 relative
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 1536), (1000, 2304, 768), (257, 128, 64)])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_linear_split_planes(gpu, M, N, K, prec):
+    """LDS-DMA GEMM on split-plane activations, fp32 and plane outputs."""
+    from avi_talking_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    xp = ops.Planes((M, K), gpu)                       # split on the host: x = hi + lo
+    hi = x.to(torch.bfloat16)
+    xp.hi.copy_(hi.view(torch.int16).to(gpu))
+    xp.lo.copy_((x - hi.float()).to(torch.bfloat16).view(torch.int16).to(gpu))
+    out = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu), prec=prec).cpu().double()
+    err = (out - ref).abs().max().item()
+    assert err < (3e-5 * math.sqrt(K / 64) if prec == 3 else 3e-2), err   # planes add 2^-17 relative on x
+
+
+def test_conv_chain_split_planes(gpu):
+    """conv0 -> conv (planes -> planes) -> conv (planes -> fp32) against torch."""
+    from avi_talking_amd import ops
+    B, N = 2, 4000 + 3
+    x = _rand((B, N), 9)
+    w0 = _rand((512, 1, 10), 10, 0.6)
+    g, b = _rand((512,), 11) * 0.1 + 1, _rand((512,), 12) * 0.1
+    w1, w2 = _rand((512, 512, 3), 13, (512 * 3) ** -0.5 * 2), _rand((512, 512, 2), 14, (512 * 2) ** -0.5 * 2)
+    h = F.gelu(F.group_norm(F.conv1d(x[:, None], w0, stride=5), 512, g, b, 1e-5))
+    ref1 = F.gelu(F.conv1d(h, w1, stride=2))
+    ref2 = F.gelu(F.conv1d(ref1, w2, stride=2)).transpose(1, 2)
+    hp = ops.conv0_gn_gelu_planes(x.to(gpu), w0.reshape(512, 10).contiguous().to(gpu), g.to(gpu), b.to(gpu))
+    assert (hp.float().cpu() - h.transpose(1, 2)).abs().max().item() < 3e-5
+    p1 = ops.PackedWeight(w1.permute(0, 2, 1).reshape(512, -1).to(gpu))
+    p2 = ops.PackedWeight(w2.permute(0, 2, 1).reshape(512, -1).to(gpu))
+    y1 = ops.conv1d_cl_planes(hp, p1, 3, 2, act=ops.ACT_GELU)
+    assert (y1.float().cpu() - ref1.transpose(1, 2)).abs().max().item() < 1e-4
+    y2 = ops.conv1d_cl_planes(y1, p2, 2, 2, act=ops.ACT_GELU, out_planes=False).cpu()
+    assert y2.shape == ref2.shape and (y2 - ref2).abs().max().item() < 1e-4
+    it = ops.interp_layernorm_planes(y1, 100).cpu()
+    ref_it = F.interpolate(ref1, size=100, align_corners=True, mode="linear").transpose(1, 2)
+    assert (it - ref_it).abs().max().item() < 1e-4
