@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libavi_talking_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("AVI_DEFINES", "").split()      # e.g. -DAVI_PP_STAMPS for scripts/pp_stamps.py
 
 
 def sources():

@@ -429,8 +429,11 @@ __global__ void pack_split_kernel(const float* __restrict__ W, int N, int K, int
 
 // gemm_dma.hip: LDS-DMA 256x128 kernel for grids that fill the chip
 int avi_gemm_dma_launch(const AviGemm& g, hipStream_t s);
+// gemm_pp.hip: 256x256 ping-pong kernel (two wave groups alternate memory and matrix sections)
+bool avi_gemm_pp_ok(const AviGemm& g);
+int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s);
 
-static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3 selects the double-buffered v2 kernel for fp32 A (experiment)
+static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3: double-buffered v2 kernel for fp32 A; =2: see below
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("AVI_GEMM_KERNEL");
@@ -464,7 +467,10 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     if (prec != AVI_PREC_BF16 && prec != AVI_PREC_BF16X3) return AVI_EINVAL;
     if ((g.scale == nullptr) != (g.shift == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (planes) return avi_gemm_dma_launch(g, s);
+    if (planes) {   // AVI_GEMM_KERNEL=2 keeps the one-phase LDS-DMA kernel (A/B experiments)
+        if (gemm_kernel_choice() != 2 && avi_gemm_pp_ok(g)) return avi_gemm_pp_launch(g, s);
+        return avi_gemm_dma_launch(g, s);
+    }
     const bool narrow = g.N <= 64;
     if (!narrow && (g.prec & 0x300) == 0) {
         if (gemm_kernel_choice() == 3) return prec == AVI_PREC_BF16X3 ? launch_gemm_v2<2>(g, s) : launch_gemm_v2<1>(g, s);

@@ -1,0 +1,381 @@
+// Third-generation GEMM for the large contractions of the audio path (conv stack, qkv, ffn): a 256 x 256 tile
+// "ping-pong" kernel.  Same contract as gemm.hip / gemm_dma.hip (C = affine(act(A.W^T + bias)) + R on split-plane
+// activations AviGemm.Ahi/Alo and bf16 hi/lo weight planes), different schedule.
+//
+// Why: the 128x128 (gemm.hip) and one-phase 256x128 LDS-DMA (gemm_dma.hip) structures both stop at ~0.86-0.9 PFLOP/s
+// of issued MFMA work: every wave does everything (stage, read fragments, multiply), so on each SIMD both resident
+// waves sit in their memory section (one LDS-DMA piece costs 100-185 issue cycles next to ds_reads) at the same time
+// and the matrix pipe idles ~55 % of the cycles.  Here the two waves of a SIMD ALTERNATE:
+//
+//   * one workgroup of 8 waves (2 along m x 4 along n, 128 x 64 outputs each) per CU, 128 KiB of LDS;
+//   * the 4 waves with wr = 1 ("group B") run ONE s_barrier behind the 4 waves with wr = 0 ("group A").  A phase is
+//       [memory section: counted vmcnt wait, 2 LDS-DMA pieces, 4 or 8 ds_read_b128]  s_barrier
+//       [matrix section: the MFMAs of one quadrant of the wave's tile (24 in bf16x3, 16 in bf16)]  s_barrier
+//     so in every barrier interval one wave of each SIMD multiplies while the other one loads;
+//   * a K tile (32 k in bf16x3: rows of [hi 64 B | lo 64 B]; 64 k in bf16: rows of 128 B) is staged as FOUR half
+//     tiles (X0 X1 W0 W1: the rows the quadrant m-half / n-half of every wave needs), two stages, one half tile per
+//     phase, each issued SIX phases before its first read.  Hazards, in phases (cdna_hip_programming.md section 5,
+//     "Read a staged buffer one phase after the wait that retires it"):
+//       RAW  the wait for a half tile read in phase q sits at the top of phase q-1 (one barrier more than a
+//            lock-step kernel needs, because group B waits one barrier later than group A reads);
+//       WAR  a slot is restaged >= 2 phases after its last ds_read (group B's read retires in its matrix section,
+//            one barrier before group A's restage).
+//     Per K tile T (stage s = T & 1):   reads            matrix quadrant   LDS-DMA issue
+//       P1                               X0(T)            (m0, n0)          X1(T+1) -> stage s^1
+//       P2                               W1(T)            (m0, n1)          W0(T+2) -> stage s
+//       P3                               X1(T)            (m1, n1)          X0(T+2) -> stage s
+//       P4                               W0(T+1)          (m1, n0)          W1(T+2) -> stage s
+//     (W0 lives in registers across the K tile, double-buffered over two K tiles: the loop is unrolled by two.)
+//     Every phase starts with `s_waitcnt vmcnt(8)`: the 4 half tiles (8 pieces per wave) issued after the one the
+//     NEXT phase reads may stay in flight - 64-80 KiB per CU is always on its way.
+//   * past the end of K the issue slots load the last K tile again into slots nobody reads any more, which keeps
+//     the vmcnt arithmetic uniform (3 % extra L2 reads at K = 1536).
+//   * LDS image and fragment addressing as in gemm_dma.hip: lane-linear LDS-DMA with the bank swizzle applied on the
+//     SOURCE address (chunk c of row R sits at c ^ (R & 7)); fragments by ds_read_b128, conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, NTHR = 512;
+constexpr int HALF_BYTES = 128 * 128;          // 128 rows x 128 B
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // X0 X1 W0 W1
+constexpr int EP_STRIDE = 272;                 // epilogue slab: 64 fp32 + 16 B pad per row
+constexpr int EP_SLAB = 64 * EP_STRIDE;        // per wave
+constexpr int SMEM_BYTES = 8 * EP_SLAB > 2 * STAGE_BYTES ? 8 * EP_SLAB : 2 * STAGE_BYTES;   // 136 KiB
+constexpr int KX0 = 0, KX1 = 1, KW0 = 2, KW1 = 3;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NS>
+__global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = tilesM * tilesN;
+    int t = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int zo = z / g.z_inner, zi = z - zo * g.z_inner;
+    const uint16_t* __restrict__ Ahi = g.Ahi + zo * g.sAo + zi * g.sAi;
+    const uint16_t* __restrict__ Alo = (NS == 2) ? g.Alo + zo * g.sAo + zi * g.sAi : Ahi;
+    const uint16_t* __restrict__ Whi = g.Whi + zo * g.sWo + zi * g.sWi;
+    const uint16_t* __restrict__ Wlo = (NS == 2) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
+
+    // ---- LDS-DMA source pointers: half tile `kind`, pieces wave and wave + 8 (1 KiB = 8 rows x 128 B each).
+    //      lane -> LDS row R = 8 piece + lane/8 of the half tile, LDS chunk lane%8 <- source chunk c = lane%8 ^ (R&7).
+    constexpr int KB = NS == 2 ? 64 : 128;   // bytes one K tile advances along a row of a plane
+    const char* src[4][2];
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int R = (wave + 8 * i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (R & 7);
+            const int off = NS == 2 ? (c & 3) * 16 : c * 16;
+            if (kind < 2) {   // activation rows: wave-row wr' = R / 64 owns rows wr' * 128 + h * 64 + R % 64
+                int m = m0 + (R >> 6) * 128 + kind * 64 + (R & 63);
+                m = m < g.M ? m : g.M - 1;
+                const uint16_t* base = (NS == 2 && c >= 4) ? Alo : Ahi;
+                src[kind][i] = reinterpret_cast<const char*>(base + (long long)m * g.lda) + off;
+            } else {          // weight rows: wave-column wc' = R / 32 owns rows wc' * 64 + h * 32 + R % 32
+                int n = n0 + (R >> 5) * 64 + (kind - 2) * 32 + (R & 31);
+                n = n < g.N ? n : g.N - 1;
+                const uint16_t* base = (NS == 2 && c >= 4) ? Wlo : Whi;
+                src[kind][i] = reinterpret_cast<const char*>(base + (long long)n * g.K) + off;
+            }
+        }
+    const int nk = g.K / (NS == 2 ? 32 : 64);   // even, >= 2 (checked by the launcher)
+
+    const bool diag_noload = g.prec & 0x100, diag_nomfma = g.prec & 0x200;   // timing diagnostics (results invalid)
+    auto issue = [&](int kind, int T, int stage) __attribute__((always_inline)) {
+        if (diag_noload && T >= 2) return;
+        const int kt = T < nk ? T : nk - 1;
+        const long long kofs = (long long)kt * KB;
+        char* dst = smem + stage * STAGE_BYTES + kind * HALF_BYTES + wave * 1024;
+        glds16(src[kind][0] + kofs, dst);
+        glds16(src[kind][1] + kofs, dst + 8 * 1024);
+    };
+
+    // ---- fragment addresses: lane (fr, fq) reads row (16-row tile base) + fr, chunks fq ("hi" position) and 4 + fq
+    const int fr = lane & 15, fq = lane >> 4;
+    const int pos = (fq ^ (fr & 7)) << 4;
+    const int xoff = (wr * 64 + fr) * 128 + pos;                     // + stage, + h * HALF, + bl * 2048
+    const int woff = 2 * HALF_BYTES + (wc * 32 + fr) * 128 + pos;    // + stage, + h * HALF, + al * 2048
+    const char* xhi_p = smem + xoff;
+    const char* xlo_p = smem + (xoff ^ 64);                          // chunk 4 + fq sits at pos ^ 64
+    const char* whi_p = smem + woff;
+    const char* wlo_p = smem + (woff ^ 64);
+
+    auto read_x = [&](int stage, int h, bf16x8 (&xh)[4], bf16x8 (&xl)[4]) __attribute__((always_inline)) {
+        const int o = stage * STAGE_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int bl = 0; bl < 4; ++bl) {
+            xh[bl] = *reinterpret_cast<const bf16x8*>(xhi_p + o + bl * 2048);
+            xl[bl] = *reinterpret_cast<const bf16x8*>(xlo_p + o + bl * 2048);
+        }
+    };
+    auto read_w = [&](int stage, int h, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) __attribute__((always_inline)) {
+        const int o = stage * STAGE_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int al = 0; al < 2; ++al) {
+            wh[al] = *reinterpret_cast<const bf16x8*>(whi_p + o + al * 2048);
+            wl[al] = *reinterpret_cast<const bf16x8*>(wlo_p + o + al * 2048);
+        }
+    };
+
+    f32x4 acc[4][8];   // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto quadrant = [&](int mh, int nh, const bf16x8 (&xh)[4], const bf16x8 (&xl)[4], const bf16x8 (&wh)[2],
+                        const bf16x8 (&wl)[2]) __attribute__((always_inline)) {
+        if (diag_nomfma) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+            for (int bl = 0; bl < 4; ++bl) {
+                f32x4 c = acc[nh * 2 + al][mh * 4 + bl];
+                if (NS == 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[al], xh[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[al], xl[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[al], xh[bl], c, 0, 0, 0);
+                } else {   // "hi"/"lo" positions are k 0..31 / 32..63 of the 64-wide K tile
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[al], xh[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[al], xl[bl], c, 0, 0, 0);
+                }
+                acc[nh * 2 + al][mh * 4 + bl] = c;
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto mem_top = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    auto bar = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#ifdef AVI_PP_STAMPS   // diagnostic build only (scripts/pp_stamps.py): g.shift is a uint64 stamp buffer when bit 0x800 is set
+    unsigned long long st[6];
+    st[0] = __builtin_amdgcn_s_memtime();
+    st[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- prologue: the 7 half tiles the steady-state schedule has in flight before phase 1 of K tile 0
+    issue(KW0, 0, 0);
+    issue(KX0, 0, 0);
+    issue(KW1, 0, 0);
+    issue(KX1, 0, 0);
+    issue(KW0, 1, 1);
+    issue(KX0, 1, 1);
+    issue(KW1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W0(0), X0(0), W1(0) have landed
+    bar();
+    bf16x8 w0h[2][2], w0l[2][2];                        // W0 fragments, double-buffered over two K tiles
+    read_w(0, 0, w0h[0], w0l[0]);
+    if (wr == 1) bar();                                 // group B runs one barrier behind group A
+
+#ifdef AVI_PP_STAMPS
+    st[1] = __builtin_amdgcn_s_memtime();
+#endif
+    bf16x8 xh[4], xl[4], w1h[2], w1l[2];
+    for (int T = 0; T < nk; T += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                   // K tile T + u in stage u
+            const int Tu = T + u;
+            // P1
+            mem_top();
+            issue(KX1, Tu + 1, u ^ 1);
+            read_x(u, 0, xh, xl);
+            bar();
+            quadrant(0, 0, xh, xl, w0h[u], w0l[u]);
+            bar();
+            // P2
+            mem_top();
+            issue(KW0, Tu + 2, u);
+            read_w(u, 1, w1h, w1l);
+            bar();
+            quadrant(0, 1, xh, xl, w1h, w1l);
+            bar();
+            // P3
+            mem_top();
+            issue(KX0, Tu + 2, u);
+            read_x(u, 1, xh, xl);
+            bar();
+            quadrant(1, 1, xh, xl, w1h, w1l);
+            bar();
+            // P4
+            mem_top();
+            issue(KW1, Tu + 2, u);
+            read_w(u ^ 1, 0, w0h[u ^ 1], w0l[u ^ 1]);   // W0 of the next K tile
+            bar();
+            quadrant(1, 0, xh, xl, w0h[u], w0l[u]);
+            bar();
+        }
+    }
+    if (wr == 0) bar();                                 // group A catches up: equal barrier counts
+
+#ifdef AVI_PP_STAMPS
+    st[2] = __builtin_amdgcn_s_memtime();
+    const bool stamps = g.prec & 0x800;
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.shift));
+    const float* gscale = stamps ? nullptr : g.scale;
+    const float* gshift = stamps ? nullptr : g.shift;
+#else
+    const float* gscale = g.scale;
+    const float* gshift = g.shift;
+#endif
+    // ---- epilogue (same contract as gemm.hip).  The accumulator layout (lane = row fr, 4 columns) would store 64-B
+    //      row segments: 256 CUs finishing their tiles together then write at ~2 TB/s and the epilogue costs a third
+    //      of the tile (measured with in-kernel stamps).  Each wave transposes its 128 x 64 block through a private
+    //      LDS slab instead (two passes of 64 rows, row stride 272 B: conflict-free b128 writes), so that 8 lanes
+    //      hold one row's 64 columns and every store instruction writes whole 128-B (plane) / 256-B (fp32) lines.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();                                              // every wave's tail DMA has landed: the stages are dead
+    float* __restrict__ C = g.C ? g.C + zo * g.sCo + zi * g.sCi : nullptr;
+    uint16_t* __restrict__ Chi = g.Chi ? g.Chi + zo * g.sCo + zi * g.sCi : nullptr;
+    uint16_t* __restrict__ Clo = g.Chi ? g.Clo + zo * g.sCo + zi * g.sCi : nullptr;
+    const float* __restrict__ bias = g.bias ? g.bias + zo * g.sBo + zi * g.sBi : nullptr;
+    const float* __restrict__ R = g.R ? g.R + zo * g.sRo + zi * g.sRi : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (!R || (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0))) &&
+                        (!Chi || (((g.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(Chi) & 15) == 0) &&
+                                  ((reinterpret_cast<uintptr_t>(Clo) & 15) == 0)));
+    char* slab = smem + wave * EP_SLAB;
+    const int ecol = (lane & 7) * 8, erow = lane >> 3;
+    const int n = n0 + wc * 64 + ecol;
+    float bv[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool in = n + j < g.N;
+        bv[j] = (bias && in) ? bias[n + j] : 0.f;
+        sc[j] = (gscale && in) ? gscale[n + j] : 1.f;
+        sh[j] = (gscale && in) ? gshift[n + j] : 0.f;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bl = 0; bl < 4; ++bl)
+                *reinterpret_cast<f32x4*>(slab + (bl * 16 + fr) * EP_STRIDE + (a * 16 + fq * 4) * 4) =
+                    pass == 0 ? acc[a][bl] : acc[a][4 + bl];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, other lanes' rows
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + erow;
+            const int m = m0 + wr * 128 + pass * 64 + row;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(slab + row * EP_STRIDE + ecol * 4);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(slab + row * EP_STRIDE + ecol * 4 + 16);
+            if (m >= g.M || n >= g.N) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = r0[j] + bv[j];
+                v[4 + j] = r1[j] + bv[4 + j];
+            }
+            if (g.act == AVI_ACT_GELU) {   // one uniform branch per 8 values, straight-line math inside
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = avi_gelu(v[j]);
+            } else if (g.act != AVI_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = avi_act(v[j], g.act);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+            if (vec_ok && n + 7 < g.N) {
+                if (R) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(R + (long long)m * g.ldr + n);
+                    const float4 q1 = *reinterpret_cast<const float4*>(R + (long long)m * g.ldr + n + 4);
+                    v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+                    v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+                }
+                if (C) {
+                    float* cp = C + (long long)m * g.ldc + n;
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (Chi) {   // split once here so the consumer GEMM never converts
+                    uint32_t h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
+                        const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
+                        h[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                        l[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                    }
+                    const long long o = (long long)m * g.ldc + n;
+                    *reinterpret_cast<uint4*>(Chi + o) = make_uint4(h[0], h[1], h[2], h[3]);
+                    *reinterpret_cast<uint4*>(Clo + o) = make_uint4(l[0], l[1], l[2], l[3]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (n + j < g.N) {
+                        const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
+                        if (C) C[(long long)m * g.ldc + n + j] = y;
+                        if (Chi) {
+                            const __bf16 hb = (__bf16)y;
+                            Chi[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, hb);
+                            Clo[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, (__bf16)(y - (float)hb));
+                        }
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the slab
+    }
+#ifdef AVI_PP_STAMPS
+    if (stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st[3] = __builtin_amdgcn_s_memtime();
+        st[5] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 || tid == 256) {
+            unsigned long long* o = stamp_out + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (tid >> 8)) * 6;
+            for (int i = 0; i < 6; ++i) o[i] = st[i];
+        }
+    }
+#endif
+}
+
+template <int NS>
+int launch(const AviGemm& g, hipStream_t s) {
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<NS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<NS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+                       tilesN);
+    return avi_launch_status();
+}
+
+}  // namespace
+
+// true when the ping-pong kernel can take the problem (K tiles come in pairs)
+bool avi_gemm_pp_ok(const AviGemm& g) {
+    const int kt = (g.prec & 0xff) == AVI_PREC_BF16X3 ? 32 : 64;
+    return g.Ahi && g.K % (2 * kt) == 0 && g.K >= 2 * kt;
+}
+
+int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s) {
+    return (g.prec & 0xff) == AVI_PREC_BF16X3 ? launch<2>(g, s) : launch<1>(g, s);
+}

@@ -36,9 +36,12 @@ class Wav2Vec2Model:
         self.device = torch.device(device)
         self.prec = prec
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
-        # AVI_W2V_PLANES=1: split-plane activations + LDS-DMA GEMM for the conv stack / qkv / ffn1 (ties with the
-        # default fp32-activation path end to end; kept as the base for further GEMM work)
-        self.use_planes = os.environ.get("AVI_W2V_PLANES", "0") == "1"
+        # Activation format.  Conv stack: bf16 hi/lo planes feeding the 256x256 ping-pong GEMM (gemm_pp.hip), each
+        # layer's epilogue emitting the next layer's planes (AVI_W2V_PLANES=0: fp32 activations + gemm.hip).
+        # Transformer: fp32 activations by default - at M = 8000 the 256x256 tiles quantise badly (288 tiles on
+        # 256 CUs for qkv) and gemm.hip's 128x128 tiles win; AVI_W2V_TF_PLANES=1 selects planes there too.
+        self.use_planes = os.environ.get("AVI_W2V_PLANES", "1") == "1"
+        self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "0") == "1"
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -120,7 +123,7 @@ class Wav2Vec2Model:
                      sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
                      sR=(T * HIDDEN, cg))
         d = HIDDEN // HEADS
-        if not self.use_planes:
+        if not self.use_planes_tf:
             h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
             for ly in self.layers:
                 qkv = ops.linear(h, ly.qkv, prec=self.prec)

@@ -6,8 +6,12 @@ from avi_talking_amd import ops
 dev = torch.device("cuda:0")
 shapes = [  # name, batch, M(per batch), N, K, lda
     ("conv1 k3s2", 32, 15999, 512, 1536, 1024),
+    ("conv2 k3s2", 32, 7999, 512, 1536, 1024),
+    ("conv3 k3s2", 32, 3999, 512, 1536, 1024),
     ("conv4 k3s2", 32, 1999, 512, 1536, 1024),
     ("conv5 k2s2", 32, 999, 512, 1024, 1024),
+    ("conv6 k2s2", 32, 499, 512, 1024, 1024),
+    ("featproj", 1, 8000, 768, 512, 512),
     ("qkv", 1, 8000, 2304, 768, 768),
     ("ffn1", 1, 8000, 3072, 768, 768),
     ("ffn2", 1, 8000, 768, 3072, 3072),

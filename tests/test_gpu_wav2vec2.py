@@ -29,18 +29,20 @@ def test_wav2vec2_parity(gpu, B, N, frame_num):
     assert e_fast < 0.15         # single-pass bf16: ~4e-3 relative per GEMM through 20 layers
 
 
-def test_wav2vec2_split_plane_path(gpu, monkeypatch):
-    """The alternative activation format (bf16 hi/lo planes + LDS-DMA GEMM) gives the same result."""
+@pytest.mark.parametrize("conv_planes,tf_planes", [("0", "0"), ("1", "1")])
+def test_wav2vec2_activation_formats(gpu, monkeypatch, conv_planes, tf_planes):
+    """The non-default activation formats (fp32 conv stack / split-plane transformer) give the same result."""
     from avi_talking_amd.weights import make_wav2vec2_weights
     from avi_talking_amd.host.wav2vec import Wav2Vec2Model
     from oracle import wav2vec2 as O
-    monkeypatch.setenv("AVI_W2V_PLANES", "1")
+    monkeypatch.setenv("AVI_W2V_PLANES", conv_planes)
+    monkeypatch.setenv("AVI_W2V_TF_PLANES", tf_planes)
     w = make_wav2vec2_weights(0)
     x = torch.randn(2, 32000, generator=torch.Generator().manual_seed(5))
     ref = O.forward(w, x)
     model = Wav2Vec2Model(w, device=gpu)
-    assert model.use_planes
+    assert model.use_planes == (conv_planes == "1") and model.use_planes_tf == (tf_planes == "1")
     out = model(x.to(gpu), "vocaset").last_hidden_state.cpu()
     err = (out - ref).abs().max().item()
-    print(f"split-plane path: last_hidden_state err {err:.3e}")
+    print(f"conv planes={conv_planes} transformer planes={tf_planes}: last_hidden_state err {err:.3e}")
     assert err < 1e-3
