@@ -226,6 +226,213 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const uint16_t* __restri
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused variant (the default): ONE launch, no scratch.  One workgroup of 8 waves per (batch, head, 256-query block):
+//   * K and V of the head are converted fp32 -> bf16 hi/lo ONCE per workgroup while they are staged into LDS
+//     (4 images of [256 keys][64 dims] bf16 = 128 KiB), so the loop never waits on global memory; the two-launch
+//     version above spends 75 us per layer in attn_prep_kernel and is latency-bound on its fragment loads from L2.
+//   * both images are ROW-major with one swizzle that serves K's row reads and V's transposed reads: the 32-B slot s
+//     of row r sits at slot s ^ ((r >> 1) & 3)  ->  ds_read_b128 (K fragment: row = key, 8 dims) and
+//     ds_read_b64_tr_b16 (V^T fragment: 4 keys x 16 dims block delivered dim-major) are both bank-conflict-free.
+//   * per wave: 2 x 16 queries (Q scaled and split in registers), same S^T = K.Q^T / O^T = V^T.P^T scheme and the same
+//     key relabelling as attn_mfma_kernel: the transposed read of the keys {4g..4g+3} and {16+4g..} of a 32-key
+//     step lands directly in the A-operand layout.
+constexpr int FCH = 256;                       // keys per LDS chunk = queries per workgroup
+constexpr int IMG = FCH * 128;                 // one image: 256 rows x 128 B
+constexpr int FUSED_SMEM = 4 * IMG;            // Khi Klo Vhi Vlo
+
+__device__ __forceinline__ int img_off(int row, int chunk) {   // byte offset of 16-B chunk `chunk` (0..7) of `row`
+    return row * 128 + (((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) << 4);
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 ld_tr2(const char* p0, const char* p1) {   // two 4-key transposed reads -> 8 keys
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict__ qkv, int T, int H, int ld,
+                                                         float scale, float* __restrict__ out, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Khi = smem;
+    char* Klo = smem + IMG;
+    char* Vhi = smem + 2 * IMG;
+    char* Vlo = smem + 3 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int fr = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * FCH + wave * 32;
+    const bool active = q0 < T;                         // wave-uniform
+    const float* base = qkv + (long long)b * T * ld + h * HD;
+
+    // ---- Q fragments: lane (q = fr, g) holds Q[q0 + 16 qt + fr][32 ks + 8 g .. +7], scaled, split
+    bf16x8 qh[2][2], ql[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + qt * 16 + fr;
+        q = q < T ? q : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* p = base + (long long)q * ld + ks * 32 + g * 8;
+            const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+            const float x[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale,
+                                c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+            split8(x, qh[qt][ks], ql[qt][ks]);
+        }
+    }
+    f32x4 acc_o[2][4];
+    float m[2], l[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[qt] = -1.0e30f;
+        l[qt] = 0.f;
+    }
+    // per-lane fragment offsets inside an image (row bases that are multiples of 16 / 32 add as immediates)
+    int kofs[2], vofs[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kofs[ks] = img_off(fr, 4 * ks + g);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)      // block row 4g + fr/4, dims 16 dt + 4 (fr%4) .. +3 (8 B)
+        vofs[dt] = img_off(4 * g + (fr >> 2), 2 * dt + ((fr & 3) >> 1)) + 8 * (fr & 1);
+
+    for (int k0 = 0; k0 < T; k0 += FCH) {
+        const int kn = (T - k0) < FCH ? (T - k0) : FCH;            // keys in this chunk
+        const int rows = (kn + 63) & ~63;                         // staged rows (whole 64-key tiles, zero padded)
+        if (k0) __syncthreads();                                  // previous chunk fully consumed
+        // ---- stage K and V: item = (row, 16-B chunk of 8 dims); 8 lanes cover one 256-B fp32 row
+        for (int it = tid; it < rows * 8; it += 512) {
+            const int row = it >> 3, c = it & 7;
+            float kx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (row < kn) {
+                const float* p = base + (long long)(k0 + row) * ld + H * HD + c * 8;
+                const float4 k0v = *reinterpret_cast<const float4*>(p), k1v = *reinterpret_cast<const float4*>(p + 4);
+                const float4 v0v = *reinterpret_cast<const float4*>(p + H * HD);
+                const float4 v1v = *reinterpret_cast<const float4*>(p + H * HD + 4);
+                kx[0] = k0v.x; kx[1] = k0v.y; kx[2] = k0v.z; kx[3] = k0v.w;
+                kx[4] = k1v.x; kx[5] = k1v.y; kx[6] = k1v.z; kx[7] = k1v.w;
+                vx[0] = v0v.x; vx[1] = v0v.y; vx[2] = v0v.z; vx[3] = v0v.w;
+                vx[4] = v1v.x; vx[5] = v1v.y; vx[6] = v1v.z; vx[7] = v1v.w;
+            }
+            bf16x8 hi, lo;
+            const int o = img_off(row, c);
+            split8(kx, hi, lo);
+            *reinterpret_cast<bf16x8*>(Khi + o) = hi;
+            *reinterpret_cast<bf16x8*>(Klo + o) = lo;
+            split8(vx, hi, lo);
+            *reinterpret_cast<bf16x8*>(Vhi + o) = hi;
+            *reinterpret_cast<bf16x8*>(Vlo + o) = lo;
+        }
+        __syncthreads();
+        if (!active) continue;                                    // wave-uniform: EXEC stays all ones below
+        for (int jl = 0; jl < rows; jl += 64) {
+            const int j0 = k0 + jl;
+            // ---- S^T tile: 4 key tiles x (16 keys x 16 queries) per query tile
+            f32x4 s[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int o = (jl + t * 16) * 128 + kofs[ks];
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + o);
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + o);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[qt][ks], s[qt][t], 0, 0, 0);
+                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[qt][ks], s[qt][t], 0, 0, 0);
+                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[qt][ks], s[qt][t], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- online softmax for query fr of each tile (keys 16 t + 4 g + r in this lane)
+            bf16x8 ph[2][2], pl[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float mx = -1.0e30f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (j0 + t * 16 + g * 4 + r >= T) s[qt][t][r] = -1.0e30f;
+                        mx = fmaxf(mx, s[qt][t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m[qt], mx);
+                const float corr = __expf(m[qt] - mn);
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = s[qt][t][r] > -1.0e29f ? __expf(s[qt][t][r] - mn) : 0.f;
+                        s[qt][t][r] = pv;
+                        sum += pv;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                l[qt] = l[qt] * corr + sum;
+                m[qt] = mn;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] *= corr;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pv = s[qt][2 * ks + (j >> 2)][j & 3];
+                        const __bf16 hi = (__bf16)pv;
+                        ph[qt][ks][j] = hi;
+                        pl[qt][ks][j] = (__bf16)(pv - (float)hi);
+                    }
+            }
+            // ---- O^T += V^T . P^T : transposed reads of keys {32 ks + 4 g ..+3} and {32 ks + 16 + 4 g ..+3}
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int o = (jl + ks * 32) * 128 + vofs[dt];
+                    const bf16x8 vh = ld_tr2(Vhi + o, Vhi + o + 16 * 128);
+                    const bf16x8 vl = ld_tr2(Vlo + o, Vlo + o + 16 * 128);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                        acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                        acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[qt][ks], acc_o[qt][dt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+        if (q0 + qt * 16 + fr < T) {
+            const float inv = 1.f / l[qt];
+            float* op = out + ((long long)b * T + q0 + qt * 16 + fr) * ldo + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(op + dt * 16) = make_float4(
+                    acc_o[qt][dt][0] * inv, acc_o[qt][dt][1] * inv, acc_o[qt][dt][2] * inv, acc_o[qt][dt][3] * inv);
+        }
+}
+
 }  // namespace
 
 // scratch: 6 * B*H*Tp*64 bf16 (= 12 * B*H*Tp*64 bytes), Tp = T rounded up to 64.
@@ -238,6 +445,18 @@ extern "C" int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, 
         return AVI_EINVAL;
     const int Tp = (T + 63) / 64 * 64;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool two_launch = [] { const char* e = getenv("AVI_ATTN_TWO_LAUNCH"); return e && atoi(e) != 0; }();
+    if (!two_launch) {   // fused: K/V converted while staged into LDS, no scratch traffic
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(attn_fused_kernel, dim3((T + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, qkv, T, H, ld,
+                           scale, out, ldo);
+        return avi_launch_status();
+    }
     hipLaunchKernelGGL(attn_prep_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, qkv, T, Tp, H, ld, scale, scratch);
     // two query tiles per wave once there are enough waves to fill the 1024 SIMDs, else one
     if ((long long)B * H * ((T + 31) / 32) >= 2048)
