@@ -249,6 +249,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
     }
 }
 
+// ------------------------------------------------------------------ split-K epilogue (skinny GEMMs of the aligner MLP)
+// y[r][:] = sum_z parts[z][r][:] + bias, then optionally LayerNorm -> act -> + residual.  One workgroup per row,
+// MAXV float4 per thread (C <= 1024 * MAXV); partial sums are added in z order, so the result is deterministic.
+template <int MAXV>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ parts, int nparts,
+                                                               long long part_stride, int C,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int do_ln,
+                                                               int act, const float* residual, float* out) {
+    __shared__ float red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = C >> 2;
+    float4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < nv) {
+            for (int z = 0; z < nparts; ++z) {
+                const float4 p = reinterpret_cast<const float4*>(parts + z * part_stride + (long long)row * C)[idx];
+                v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
+            }
+            if (bias) {
+                const float4 b = reinterpret_cast<const float4*>(bias)[idx];
+                v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w;
+            }
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (do_ln) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        s = wave_sum(s);
+        if (lane == 0) red[0][wave] = s;
+        __syncthreads();
+        mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (tid + 256 * i < nv) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + c * c + d * d;
+            }
+        q = wave_sum(q);
+        if (lane == 0) red[1][wave] = q;
+        __syncthreads();
+        rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / C + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx >= nv) continue;
+        float4 r = v[i];
+        if (do_ln) {
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gamma) g = reinterpret_cast<const float4*>(gamma)[idx];
+            if (beta) bb = reinterpret_cast<const float4*>(beta)[idx];
+            r.x = (r.x - mean) * rstd * g.x + bb.x;
+            r.y = (r.y - mean) * rstd * g.y + bb.y;
+            r.z = (r.z - mean) * rstd * g.z + bb.z;
+            r.w = (r.w - mean) * rstd * g.w + bb.w;
+        }
+        r.x = avi_act(r.x, act); r.y = avi_act(r.y, act); r.z = avi_act(r.z, act); r.w = avi_act(r.w, act);
+        if (residual) {
+            const float4 rr = reinterpret_cast<const float4*>(residual + (long long)row * C)[idx];
+            r.x += rr.x; r.y += rr.y; r.z += rr.z; r.w += rr.w;
+        }
+        reinterpret_cast<float4*>(out + (long long)row * C)[idx] = r;
+    }
+}
+
 // out[b][t] = LN( lerp(in[b][i0], in[b][i1]) ), align_corners=True index math of
 // torch upsample_linear1d: scale = (Tin-1)/(Tout-1), src = scale*t, i0 = (int)src, l1 = src - i0.
 template <int MAXV>
@@ -458,6 +531,21 @@ extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* g
     else
         hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
                            stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr);
+    return avi_launch_status();
+}
+
+extern "C" int avi_splitk_epilogue(const float* parts, int nparts, long long part_stride, int rows, int C,
+                                   const float* bias, const float* gamma, const float* beta, float eps, int do_ln,
+                                   int act, const float* residual, float* out, void* stream) {
+    if (!parts || !out || nparts < 1 || rows <= 0 || C <= 0 || (C & 3) || C > 4096 || (part_stride & 3))
+        return AVI_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C <= 1024)
+        hipLaunchKernelGGL(splitk_epilogue_kernel<1>, dim3(rows), dim3(256), 0, s, parts, nparts, part_stride, C, bias,
+                           gamma, beta, eps, do_ln, act, residual, out);
+    else
+        hipLaunchKernelGGL(splitk_epilogue_kernel<4>, dim3(rows), dim3(256), 0, s, parts, nparts, part_stride, C, bias,
+                           gamma, beta, eps, do_ln, act, residual, out);
     return avi_launch_status();
 }
 

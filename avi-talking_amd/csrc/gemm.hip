@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
     const uint16_t* wlp[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const long long off = (long long)(n0 + r0 + 32 * i) * g.K + c * 8;
+        const long long off = (long long)(n0 + r0 + 32 * i) * (g.ldw ? g.ldw : g.K) + c * 8;
         whp[i] = Whi + off;
         wlp[i] = (NS == 2) ? Wlo + off : nullptr;
     }
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const AviGemm g, const 
     int mrow = m0 + r;
     mrow = mrow < g.M ? mrow : g.M - 1;
     const float* ap = A + (long long)mrow * g.lda + hf * 16;
-    const uint16_t* whp = Whi + (long long)(n0 + r) * g.K + hf * 16;
-    const uint16_t* wlp = (NS == 2) ? Wlo + (long long)(n0 + r) * g.K + hf * 16 : nullptr;
+    const uint16_t* whp = Whi + (long long)(n0 + r) * (g.ldw ? g.ldw : g.K) + hf * 16;
+    const uint16_t* wlp = (NS == 2) ? Wlo + (long long)(n0 + r) * (g.ldw ? g.ldw : g.K) + hf * 16 : nullptr;
     const int sw = r & 7;
     const int o_h0 = r * 128 + (((2 * hf) ^ sw) << 4), o_h1 = r * 128 + (((2 * hf + 1) ^ sw) << 4);
     const int o_l0 = r * 128 + (((4 + 2 * hf) ^ sw) << 4), o_l1 = r * 128 + (((5 + 2 * hf) ^ sw) << 4);
@@ -448,6 +448,7 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     const bool planes = g.Ahi != nullptr;
     if ((!g.A && !planes) || !g.Whi || (!g.C && !g.Chi) || g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0)
         return AVI_EINVAL;
+    if (g.ldw && (g.ldw < g.K || (g.ldw & 7))) return AVI_EINVAL;
     if (g.batch < 1 || g.z_inner < 1 || (g.batch % g.z_inner) != 0 || g.batch > 65535) return AVI_EINVAL;
     if ((g.Chi == nullptr) != (g.Clo == nullptr)) return AVI_EINVAL;
     if (g.Chi && ((g.ldc & 3) || (g.sCo & 3) || (g.sCi & 3) || (reinterpret_cast<uintptr_t>(g.Chi) & 7) ||

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_dma_kernel(const AviGemm g, cons
         const int r = (i * 8 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ fW(r & 15);
         const uint16_t* base = (c < 4 || NS == 1) ? Whi : Wlo;
-        wsrc[i] = reinterpret_cast<const char*>(base + (long long)(n0 + r) * g.K) + (c & 3) * 16;
+        wsrc[i] = reinterpret_cast<const char*>(base + (long long)(n0 + r) * (g.ldw ? g.ldw : g.K)) + (c & 3) * 16;
         wact[i] = (NS == 2) || (c < 4);
     }
 

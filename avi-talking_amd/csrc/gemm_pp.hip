@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
                 int n = n0 + (R >> 5) * 64 + (kind - 2) * 32 + (R & 31);
                 n = n < g.N ? n : g.N - 1;
                 const uint16_t* base = (NS == 2 && c >= 4) ? Wlo : Whi;
-                src[kind][i] = reinterpret_cast<const char*>(base + (long long)n * g.K) + off;
+                src[kind][i] = reinterpret_cast<const char*>(base + (long long)n * (g.ldw ? g.ldw : g.K)) + off;
             }
         }
     const int nk = g.K / (NS == 2 ? 32 : 64);   // even, >= 2 (checked by the launcher)

@@ -84,10 +84,15 @@ class BrainNetwork:
         self.pn = [(w[f"projector.{i}.weight"], w[f"projector.{i}.bias"]) for i in (0, 3, 6)]
         self.pl = [P(w[f"projector.{i}.weight"], w[f"projector.{i}.bias"]) for i in (2, 5, 8)]
 
-    def forward(self, x):
+    def forward(self, x, need_projection=True):
+        """-> (backbone output (B,128), projector output (B,1,128)); ``need_projection=False`` skips the projector
+        head (returns None for it): the sampling entry point only consumes the backbone output
+        (train_diffusion_prior.py:783-853)."""
         x = x.to(self.device, torch.float32).contiguous()
         if x.dim() != 2:
             x = x.reshape(x.shape[0], -1)
+        if x.shape[0] <= 32 and x.shape[1] % 64 == 0:
+            return self._forward_skinny(x, need_projection)
         h = ops.linear(x, self.lin0, prec=self.prec)
         h = ops.layernorm(h, *self.ln0, act=ops.ACT_GELU, out=h)              # Linear -> LN -> GELU (-> Dropout off)
         for pw, ln in self.mlp:
@@ -100,6 +105,22 @@ class BrainNetwork:
         z = ops.linear(z, self.pl[1], prec=self.prec)
         z = ops.layernorm(z, *self.pn[2], act=ops.ACT_GELU, out=z)
         z = ops.linear(z, self.pl[2], prec=self.prec)
+        return out, z.view(out.shape[0], -1, self.clip_size)
+
+    def _forward_skinny(self, x, need_projection):
+        """Same network for <= 32 rows: every Linear is a split-K batched launch whose epilogue kernel folds the
+        partial sums and applies bias -> LayerNorm -> GELU (-> + residual) (ops.linear_ln_skinny)."""
+        S, G = ops.linear_ln_skinny, ops.ACT_GELU
+        h = S(x, self.lin0, *self.ln0, act=G, prec=self.prec)
+        for pw, ln in self.mlp:
+            h = S(h, pw, *ln, act=G, residual=h, prec=self.prec)
+        out = S(h, self.lin1, do_ln=False, prec=self.prec)
+        if not need_projection:
+            return out, None
+        z = ops.layernorm(out, *self.pn[0], act=G)
+        z = S(z, self.pl[0], *self.pn[1], act=G, prec=self.prec)
+        z = S(z, self.pl[1], *self.pn[2], act=G, prec=self.prec)
+        z = S(z, self.pl[2], do_ln=False, prec=self.prec)
         return out, z.view(out.shape[0], -1, self.clip_size)
 
     __call__ = forward

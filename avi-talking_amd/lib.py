@@ -30,6 +30,7 @@ class AviGemm(C.Structure):
         ("batch", _i), ("z_inner", _i),
         ("act", _i), ("prec", _i),
         ("Ahi", _vp), ("Alo", _vp), ("Chi", _vp), ("Clo", _vp),
+        ("ldw", _i),
     ]
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "avi_splitk_epilogue": [_vp, _i, _ll, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_layernorm_act": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],

@@ -40,9 +40,10 @@ class PackedWeight:
 
 def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
              prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0),
-             Ahi=0, Alo=0, Chi=0, Clo=0):
+             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0):
     """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets)."""
     g = L.AviGemm()
+    g.ldw = ldw
     g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
     g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
@@ -160,6 +161,36 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, act=ACT_NONE, residual=None):
         raise ValueError("layernorm: bad residual shape")
     L.check(L.load().avi_layernorm_act(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps, act, L.ptr(residual),
                                        out.data_ptr(), L.stream_ptr()), "avi_layernorm_act")
+    return out
+
+
+def linear_ln_skinny(x, pw, gamma=None, beta=None, eps=1e-5, do_ln=True, act=ACT_NONE, residual=None,
+                     prec=PREC_BF16X3, kslice=256):
+    """out = act(LN(x @ W^T + b)) + residual for a handful of rows (M <= 32: the aligner MLP at batch-size rows).
+
+    A 128-row GEMM tile would be three quarters padding and a 4096-long K loop on 32 workgroups is pure latency,
+    so K is cut into slices that run as one batched launch (hundreds of workgroups stream the weight matrix at
+    HBM speed); ``avi_splitk_epilogue`` folds the partial sums, adds the bias and applies LN/act/residual."""
+    x = _f32c(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    if K != pw.K:
+        raise ValueError(f"linear_ln_skinny: x has K={K}, weight has K={pw.K}")
+    while K % kslice:
+        kslice //= 2
+    if kslice < 64:
+        raise ValueError("linear_ln_skinny: K must be a multiple of 64")
+    nz = K // kslice
+    N = pw.N
+    parts = torch.empty((nz, M, N), dtype=torch.float32, device=x.device)
+    gemm_raw(A=x.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=parts.data_ptr(), ldc=N, M=M, N=N,
+             K=kslice, prec=prec, batch=nz, sA=(kslice, 0), sW=(kslice, 0), sC=(M * N, 0), ldw=K)
+    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    if residual is not None and _f32c(residual, "residual").numel() != out.numel():
+        raise ValueError("linear_ln_skinny: bad residual shape")
+    L.check(L.load().avi_splitk_epilogue(parts.data_ptr(), nz, M * N, M, N, L.ptr(pw.bias), L.ptr(gamma), L.ptr(beta),
+                                         eps, int(do_ln), act, L.ptr(residual), out.data_ptr(), L.stream_ptr()),
+            "avi_splitk_epilogue")
     return out
 
 

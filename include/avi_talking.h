@@ -72,6 +72,10 @@ typedef struct AviGemm {
      * planes with row stride ldc (C may then be NULL), so chains of GEMMs never pass through fp32. */
     const uint16_t *Ahi, *Alo;
     uint16_t *Chi, *Clo;
+    /* Row stride of the weight planes in elements (0 = K).  With ldw > K a batch of launches can walk K slices of
+     * one weight matrix (split-K for skinny problems: sAo = sWo = K_slice, partial sums per batch entry, folded by
+     * avi_splitk_epilogue). */
+    int ldw;
 } AviGemm;
 int avi_gemm(const AviGemm* g, void* stream);
 
@@ -108,6 +112,14 @@ int avi_interp_layernorm_planes(const uint16_t* in_hi, const uint16_t* in_lo, in
 /* row LayerNorm: out[r] = LN(in[r]) * gamma + beta, rows x C.  in == out allowed. */
 int avi_layernorm(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
                   float* out, void* stream);
+/* Split-K epilogue for skinny GEMMs (M <= 32: the aligner MLP, models/diffusion_prior.py:58-117, whose Linear ->
+ * LayerNorm -> GELU (+ residual) blocks run at batch-size rows): y[r][:] = sum_z parts[z*part_stride + r*C ..] + bias,
+ * then, if do_ln, LayerNorm(gamma, beta, eps); then act; then + residual.  Partials are added in z order.
+ * C % 4 == 0, C <= 4096. */
+int avi_splitk_epilogue(const float* parts, int nparts, long long part_stride, int rows, int C, const float* bias,
+                        const float* gamma, const float* beta, float eps, int do_ln, int act, const float* residual,
+                        float* out, void* stream);
+
 /* LayerNorm whose result is written as fp32 (out, may be NULL) and as bf16 hi/lo planes (the next GEMM's operand) */
 int avi_layernorm_planes(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
                          float* out, uint16_t* out_hi, uint16_t* out_lo, void* stream);

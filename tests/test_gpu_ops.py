@@ -208,3 +208,23 @@ def test_conv_chain_split_planes(gpu):
     it = ops.interp_layernorm_planes(y1, 100).cpu()
     ref_it = F.interpolate(ref1, size=100, align_corners=True, mode="linear").transpose(1, 2)
     assert (it - ref_it).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,do_ln,res", [(32, 4096, 4096, True, True), (7, 4096, 768, True, False),
+                                             (32, 128, 4096, False, False), (1, 2048, 128, True, False)])
+def test_linear_ln_skinny(gpu, M, N, K, do_ln, res):
+    """Split-K linear for a handful of rows + fused bias/LayerNorm/GELU/residual epilogue."""
+    from avi_talking_amd import ops
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    gm, bt, r = 1 + 0.1 * _rand((N,), 4), 0.1 * _rand((N,), 5), _rand((M, N), 6)
+    ref = F.linear(x.double(), w.double(), b.double())
+    if do_ln:
+        ref = F.gelu(F.layer_norm(ref, (N,), gm.double(), bt.double(), 1e-5))
+    if res:
+        ref = ref + r.double()
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    out = ops.linear_ln_skinny(x.to(gpu), pw, gm.to(gpu) if do_ln else None, bt.to(gpu) if do_ln else None,
+                               do_ln=do_ln, act=ops.ACT_GELU if do_ln else ops.ACT_NONE,
+                               residual=r.to(gpu) if res else None)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 5e-5, err

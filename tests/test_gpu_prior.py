@@ -30,6 +30,11 @@ def test_brain_network_parity(gpu, pw):
     a, b = net(x.to(gpu))
     print("brain err", (a.cpu() - ra).abs().max().item(), (b.cpu() - rb).abs().max().item())
     assert (a.cpu() - ra).abs().max().item() < 2e-4 and (b.cpu() - rb).abs().max().item() < 2e-4
+    # <= 32 rows take the split-K path (batched K slices + avi_splitk_epilogue); 64 rows above took the tiled GEMMs
+    a32, b32 = net(x[:32].to(gpu))
+    assert (a32.cpu() - ra[:32]).abs().max().item() < 2e-4 and (b32.cpu() - rb[:32]).abs().max().item() < 2e-4
+    a5, none = net(x[:5].to(gpu), need_projection=False)
+    assert none is None and (a5.cpu() - ra[:5]).abs().max().item() < 2e-4
 
 
 def test_prior_step_parity(gpu, pw):
