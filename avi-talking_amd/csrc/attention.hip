@@ -167,6 +167,11 @@ int launch_attention(const float* q, const float* k, const float* v, float* out,
 
 }  // namespace
 
+// attention_mfma.hip: fused matrix-core kernel (bf16x3 operands, K/V staged once per head into LDS)
+int avi_attention_fused_launch(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk,
+                               int D, int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes,
+                               int period, hipStream_t s);
+
 extern "C" int avi_attention(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq,
                              int Tk, int D, int ldq, int ldk, int ldo, float scale, int bias_mode,
                              const float* slopes, int period, void* stream) {
@@ -176,6 +181,13 @@ extern "C" int avi_attention(const float* q, const float* k, const float* v, flo
     if (bias_mode == 2 && period < 1) return AVI_EINVAL;
     if ((long long)B * H > 65535) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // head dims 16/32/64 run on the matrix cores (the fp32 vector kernel below keeps 3/4 of its lanes idle in the
+    // P.V phase at D = 16); AVI_ATTN_VALU=1 forces the vector kernel (A/B checks), which also serves D = 128 / 256
+    static const bool force_valu = [] { const char* e = getenv("AVI_ATTN_VALU"); return e && atoi(e) != 0; }();
+    const bool aligned16 = !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                              reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) && !(ldo & 3);
+    if (!force_valu && aligned16 && (D == 16 || D == 32 || D == 64))
+        return avi_attention_fused_launch(q, k, v, out, B, H, Tq, Tk, D, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
 #define AVI_ATT_CASE(DD) \
     case DD: return launch_attention<DD>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
     switch (D) {

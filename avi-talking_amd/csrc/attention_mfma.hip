@@ -246,12 +246,12 @@ __device__ __forceinline__ int img_off(int row, int chunk) {   // byte offset of
 }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ bf16x8 ld_tr2(const char* p0, const char* p1) {   // two 4-key transposed reads -> 8 keys
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -265,8 +265,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
     }
 }
 
-__global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict__ qkv, int T, int H, int ld,
-                                                         float scale, float* __restrict__ out, int ldo) {
+// Head dims 16, 32 and 64; additive score biases of the reference restated analytically (attention.hip, modes 1/2).
+//   D = 16 uses v_mfma_f32_16x16x16_bf16 for S^T (the whole head dim is one k-step of 16); images keep 128-B rows
+//   for every D (the first 2 D bytes hold data), so one swizzle/offset function serves all three.
+template <int D>
+__global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+                                                         const float* __restrict__ vp, int Tq, int Tk, int H, int ldq,
+                                                         int ldk, float scale, int bias_mode,
+                                                         const float* __restrict__ slopes, int period,
+                                                         float* __restrict__ out, int ldo) {
+    constexpr int KS = D >= 32 ? D / 32 : 1;      // k-steps of the score product
+    constexpr int DT = D / 16;                    // 16-dim tiles of the output
+    constexpr int CH = D / 8;                     // 16-B chunks (8 dims) per image row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Khi = smem;
     char* Klo = smem + IMG;
@@ -277,54 +287,72 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int fr = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * FCH + wave * 32;
-    const bool active = q0 < T;                         // wave-uniform
-    const float* base = qkv + (long long)b * T * ld + h * HD;
+    const bool active = q0 < Tq;                         // wave-uniform
+    const float* qbase = qp + (long long)b * Tq * ldq + h * D;
+    const float* kbase = kp + (long long)b * Tk * ldk + h * D;
+    const float* vbase = vp + (long long)b * Tk * ldk + h * D;
+    const float slope = (bias_mode != 0 && slopes) ? slopes[h] : 0.f;
 
-    // ---- Q fragments: lane (q = fr, g) holds Q[q0 + 16 qt + fr][32 ks + 8 g .. +7], scaled, split
-    bf16x8 qh[2][2], ql[2][2];
+    // ---- Q fragments (B operand of S^T): lane (q = fr, g), scaled, split
+    //      D >= 32: Q[q][32 ks + 8 g .. +7];   D = 16: Q[q][4 g .. +3] in elements 0..3
+    bf16x8 qh[2][KS], ql[2][KS];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         int q = q0 + qt * 16 + fr;
-        q = q < T ? q : T - 1;
+        q = q < Tq ? q : Tq - 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const float* p = base + (long long)q * ld + ks * 32 + g * 8;
-            const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
-            const float x[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale,
-                                c.x * scale, c.y * scale, c.z * scale, c.w * scale};
+        for (int ks = 0; ks < KS; ++ks) {
+            float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (D >= 32) {
+                const float* p = qbase + (long long)q * ldq + ks * 32 + g * 8;
+                const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+                x[0] = a.x * scale; x[1] = a.y * scale; x[2] = a.z * scale; x[3] = a.w * scale;
+                x[4] = c.x * scale; x[5] = c.y * scale; x[6] = c.z * scale; x[7] = c.w * scale;
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(qbase + (long long)q * ldq + g * 4);
+                x[0] = a.x * scale; x[1] = a.y * scale; x[2] = a.z * scale; x[3] = a.w * scale;
+            }
             split8(x, qh[qt][ks], ql[qt][ks]);
         }
     }
-    f32x4 acc_o[2][4];
+    f32x4 acc_o[2][DT];
     float m[2], l[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) acc_o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         m[qt] = -1.0e30f;
         l[qt] = 0.f;
     }
     // per-lane fragment offsets inside an image (row bases that are multiples of 16 / 32 add as immediates)
-    int kofs[2], vofs[4];
+    int kofs[KS], vofs[DT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) kofs[ks] = img_off(fr, 4 * ks + g);
+    for (int ks = 0; ks < KS; ++ks)
+        kofs[ks] = D >= 32 ? img_off(fr, 4 * ks + g) : img_off(fr, g >> 1) + 8 * (g & 1);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)      // block row 4g + fr/4, dims 16 dt + 4 (fr%4) .. +3 (8 B)
+    for (int dt = 0; dt < DT; ++dt)      // block row 4g + fr/4, dims 16 dt + 4 (fr%4) .. +3 (8 B)
         vofs[dt] = img_off(4 * g + (fr >> 2), 2 * dt + ((fr & 3) >> 1)) + 8 * (fr & 1);
 
-    for (int k0 = 0; k0 < T; k0 += FCH) {
-        const int kn = (T - k0) < FCH ? (T - k0) : FCH;            // keys in this chunk
+    // causal mode never needs keys past the workgroup's last query row
+    int kend = Tk;
+    if (bias_mode == 2) {
+        const int lastq = blockIdx.x * FCH + FCH - 1 < Tq ? blockIdx.x * FCH + FCH - 1 : Tq - 1;
+        kend = lastq + 1 < Tk ? lastq + 1 : Tk;
+    }
+    for (int k0 = 0; k0 < kend; k0 += FCH) {
+        const int kn = (kend - k0) < FCH ? (kend - k0) : FCH;     // keys in this chunk
         const int rows = (kn + 63) & ~63;                         // staged rows (whole 64-key tiles, zero padded)
         if (k0) __syncthreads();                                  // previous chunk fully consumed
-        // ---- stage K and V: item = (row, 16-B chunk of 8 dims); 8 lanes cover one 256-B fp32 row
-        for (int it = tid; it < rows * 8; it += 512) {
-            const int row = it >> 3, c = it & 7;
+        // ---- stage K and V: item = (row, 16-B chunk of 8 dims); CH lanes cover one fp32 row of the head
+        for (int it = tid; it < rows * CH; it += 512) {
+            const int row = it / CH, c = it - row * CH;
             float kx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (row < kn) {
-                const float* p = base + (long long)(k0 + row) * ld + H * HD + c * 8;
-                const float4 k0v = *reinterpret_cast<const float4*>(p), k1v = *reinterpret_cast<const float4*>(p + 4);
-                const float4 v0v = *reinterpret_cast<const float4*>(p + H * HD);
-                const float4 v1v = *reinterpret_cast<const float4*>(p + H * HD + 4);
+                const long long o = (long long)(k0 + row) * ldk + c * 8;
+                const float4 k0v = *reinterpret_cast<const float4*>(kbase + o);
+                const float4 k1v = *reinterpret_cast<const float4*>(kbase + o + 4);
+                const float4 v0v = *reinterpret_cast<const float4*>(vbase + o);
+                const float4 v1v = *reinterpret_cast<const float4*>(vbase + o + 4);
                 kx[0] = k0v.x; kx[1] = k0v.y; kx[2] = k0v.z; kx[3] = k0v.w;
                 kx[4] = k1v.x; kx[5] = k1v.y; kx[6] = k1v.z; kx[7] = k1v.w;
                 vx[0] = v0v.x; vx[1] = v0v.y; vx[2] = v0v.z; vx[3] = v0v.w;
@@ -350,15 +378,30 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     const int o = (jl + t * 16) * 128 + kofs[ks];
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + o);
-                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + o);
+                    if (D >= 32) {
+                        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + o);
+                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + o);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
-                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[qt][ks], s[qt][t], 0, 0, 0);
-                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[qt][ks], s[qt][t], 0, 0, 0);
-                        s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[qt][ks], s[qt][t], 0, 0, 0);
+                        for (int qt = 0; qt < 2; ++qt) {
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[qt][ks], s[qt][t], 0, 0, 0);
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[qt][ks], s[qt][t], 0, 0, 0);
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[qt][ks], s[qt][t], 0, 0, 0);
+                        }
+                    } else {   // lane (key = fr, g) holds K[key][4 g .. +3]
+                        const s16x4 kh = *reinterpret_cast<const s16x4*>(Khi + o);
+                        const s16x4 kl = *reinterpret_cast<const s16x4*>(Klo + o);
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt) {
+                            const s16x4 bh_ = __builtin_shufflevector(__builtin_bit_cast(s16x8, qh[qt][0]),
+                                                                      __builtin_bit_cast(s16x8, qh[qt][0]), 0, 1, 2, 3);
+                            const s16x4 bl_ = __builtin_shufflevector(__builtin_bit_cast(s16x8, ql[qt][0]),
+                                                                      __builtin_bit_cast(s16x8, ql[qt][0]), 0, 1, 2, 3);
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kl, bh_, s[qt][t], 0, 0, 0);
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kh, bl_, s[qt][t], 0, 0, 0);
+                            s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kh, bh_, s[qt][t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -366,13 +409,25 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
             bf16x8 ph[2][2], pl[2][2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
+                const int qi = q0 + qt * 16 + fr;
                 float mx = -1.0e30f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (j0 + t * 16 + g * 4 + r >= T) s[qt][t][r] = -1.0e30f;
-                        mx = fmaxf(mx, s[qt][t][r]);
+                        const int j = j0 + t * 16 + g * 4 + r;
+                        float sv = s[qt][t][r];
+                        bool valid = j < Tk;
+                        if (bias_mode == 1) {          // inferno TransformerMasking.py:80-98
+                            const int dlt = qi > j ? qi - j : j - qi;
+                            sv -= slope * (float)dlt;
+                        } else if (bias_mode == 2) {   // models/faceformer.py:51-72
+                            valid = valid && (j <= qi);
+                            sv -= slope * (float)((qi - j) / period);
+                        }
+                        sv = valid ? sv : -1.0e30f;
+                        s[qt][t][r] = sv;
+                        mx = fmaxf(mx, sv);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -392,7 +447,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                 l[qt] = l[qt] * corr + sum;
                 m[qt] = mn;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc_o[qt][dt] *= corr;
+                for (int dt = 0; dt < DT; ++dt) acc_o[qt][dt] *= corr;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -405,7 +460,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
             }
             // ---- O^T += V^T . P^T : transposed reads of keys {32 ks + 4 g ..+3} and {32 ks + 16 + 4 g ..+3}
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int o = (jl + ks * 32) * 128 + vofs[dt];
@@ -423,14 +478,28 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
     if (!active) return;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
-        if (q0 + qt * 16 + fr < T) {
+        if (q0 + qt * 16 + fr < Tq) {
             const float inv = 1.f / l[qt];
-            float* op = out + ((long long)b * T + q0 + qt * 16 + fr) * ldo + h * HD + g * 4;
+            float* op = out + ((long long)b * Tq + q0 + qt * 16 + fr) * ldo + h * D + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
                 *reinterpret_cast<float4*>(op + dt * 16) = make_float4(
                     acc_o[qt][dt][0] * inv, acc_o[qt][dt][1] * inv, acc_o[qt][dt][2] * inv, acc_o[qt][dt][3] * inv);
         }
+}
+
+template <int D>
+int launch_fused(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk, int ldq,
+                 int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_fused_kernel<D>, dim3((Tq + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, q, k, v, Tq, Tk,
+                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo);
+    return avi_launch_status();
 }
 
 }  // namespace
@@ -446,17 +515,8 @@ extern "C" int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, 
     const int Tp = (T + 63) / 64 * 64;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const bool two_launch = [] { const char* e = getenv("AVI_ATTN_TWO_LAUNCH"); return e && atoi(e) != 0; }();
-    if (!two_launch) {   // fused: K/V converted while staged into LDS, no scratch traffic
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(attn_fused_kernel, dim3((T + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, qkv, T, H, ld,
-                           scale, out, ldo);
-        return avi_launch_status();
-    }
+    if (!two_launch)     // fused: K/V converted while staged into LDS, no scratch traffic
+        return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, 0, nullptr, 1, s);
     hipLaunchKernelGGL(attn_prep_kernel, dim3(Tp / 64, B * H), dim3(256), 0, s, qkv, T, Tp, H, ld, scale, scratch);
     // two query tiles per wave once there are enough waves to fill the 1024 SIMDs, else one
     if ((long long)B * H * ((T + 31) / 32) >= 2048)
@@ -464,4 +524,16 @@ extern "C" int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, 
     else
         hipLaunchKernelGGL(attn_mfma_kernel<1>, dim3(Tp / 64, B * H), dim3(256), 0, s, scratch, T, Tp, H, ldo, out);
     return avi_launch_status();
+}
+
+// Matrix-core path of avi_attention (attention.hip) for head dims 16 / 32 / 64; strides and pointers 16-B aligned.
+int avi_attention_fused_launch(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk,
+                               int D, int ldq, int ldk, int ldo, float scale, int bias_mode, const float* slopes,
+                               int period, hipStream_t s) {
+    switch (D) {
+        case 16: return launch_fused<16>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
+        case 32: return launch_fused<32>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
+        case 64: return launch_fused<64>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
+        default: return AVI_EINVAL;
+    }
 }

@@ -116,8 +116,10 @@ def _slopes(n):
 
 
 @pytest.mark.parametrize("H,D,T,mode", [(12, 64, 250, 0), (8, 16, 97, 0), (8, 32, 256, 1), (4, 16, 130, 2),
-                                        (4, 256, 70, 2), (2, 128, 65, 0)])
+                                        (4, 256, 70, 2), (2, 128, 65, 0), (8, 16, 250, 1), (4, 32, 500, 1),
+                                        (2, 32, 300, 2), (2, 64, 700, 2)])
 def test_attention(gpu, H, D, T, mode):
+    """avi_attention: head dims 16/32/64 on the matrix cores (bf16x3 operands), the fp32 vector kernel for the rest."""
     from avi_talking_amd import ops
     B = 2
     qkv = _rand((B, T, 3 * H * D), 20)
@@ -136,7 +138,8 @@ def test_attention(gpu, H, D, T, mode):
     dq = qkv.to(gpu)
     out = ops.attention(dq[..., :H * D], dq[..., H * D:2 * H * D], dq[..., 2 * H * D:], H, D, 3 * H * D, 3 * H * D,
                         T, T, B, D ** -0.5, bias_mode=mode, slopes=slopes.to(gpu), period=period).cpu()
-    assert (out - ref).abs().max().item() < 2e-5
+    err = (out - ref).abs().max().item()
+    assert err < (2e-5 if D > 64 else 5e-5), err      # MFMA path: operands split into bf16 hi+lo (~1e-5 relative)
 
 
 def test_pad_repeat_and_pack(gpu):
