@@ -273,7 +273,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                                                          const float* __restrict__ vp, int Tq, int Tk, int H, int ldq,
                                                          int ldk, float scale, int bias_mode,
                                                          const float* __restrict__ slopes, int period,
-                                                         float* __restrict__ out, int ldo) {
+                                                         float* __restrict__ out, int ldo,
+                                                         uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo) {
     constexpr int KS = D >= 32 ? D / 32 : 1;      // k-steps of the score product
     constexpr int DT = D / 16;                    // 16-dim tiles of the output
     constexpr int CH = D / 8;                     // 16-B chunks (8 dims) per image row
@@ -480,17 +481,32 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
     for (int qt = 0; qt < 2; ++qt)
         if (q0 + qt * 16 + fr < Tq) {
             const float inv = 1.f / l[qt];
-            float* op = out + ((long long)b * Tq + q0 + qt * 16 + fr) * ldo + h * D + g * 4;
+            const long long o = ((long long)b * Tq + q0 + qt * 16 + fr) * ldo + h * D + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                *reinterpret_cast<float4*>(op + dt * 16) = make_float4(
-                    acc_o[qt][dt][0] * inv, acc_o[qt][dt][1] * inv, acc_o[qt][dt][2] * inv, acc_o[qt][dt][3] * inv);
+            for (int dt = 0; dt < DT; ++dt) {
+                const float v[4] = {acc_o[qt][dt][0] * inv, acc_o[qt][dt][1] * inv, acc_o[qt][dt][2] * inv,
+                                    acc_o[qt][dt][3] * inv};
+                if (out) *reinterpret_cast<float4*>(out + o + dt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                if (out_hi) {   // split planes for the consumer GEMM (x = hi + lo)
+                    uint32_t hh[2], ll[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
+                        const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
+                        hh[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                        ll[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                    }
+                    *reinterpret_cast<uint2*>(out_hi + o + dt * 16) = make_uint2(hh[0], hh[1]);
+                    *reinterpret_cast<uint2*>(out_lo + o + dt * 16) = make_uint2(ll[0], ll[1]);
+                }
+            }
         }
 }
 
 template <int D>
 int launch_fused(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk, int ldq,
-                 int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period, hipStream_t s) {
+                 int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period, hipStream_t s,
+                 uint16_t* out_hi = nullptr, uint16_t* out_lo = nullptr) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<D>),
@@ -498,7 +514,7 @@ int launch_fused(const float* q, const float* k, const float* v, float* out, int
         attr_done = true;
     }
     hipLaunchKernelGGL(attn_fused_kernel<D>, dim3((Tq + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, q, k, v, Tq, Tk,
-                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo);
+                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo);
     return avi_launch_status();
 }
 
@@ -536,4 +552,17 @@ int avi_attention_fused_launch(const float* q, const float* k, const float* v, f
         case 64: return launch_fused<64>(q, k, v, out, B, H, Tq, Tk, ldq, ldk, ldo, scale, bias_mode, slopes, period, s);
         default: return AVI_EINVAL;
     }
+}
+
+// Head-dim-64 attention over a packed QKV projection whose result is written as split bf16 planes (and optionally as
+// fp32 too): the operand format of the ping-pong GEMM that consumes it (the encoder's out_proj).
+extern "C" int avi_attention_d64_planes(const float* qkv, int B, int H, int T, int ld, float scale, float* out,
+                                        uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+    if (!qkv || !out_hi || !out_lo || B <= 0 || H <= 0 || T <= 0 || (ld & 3) || (ldo & 3)) return AVI_EINVAL;
+    if (ld < 3 * H * HD || ldo < H * HD || (long long)B * H > 65535) return AVI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+        ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 7))
+        return AVI_EINVAL;
+    return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, 0, nullptr, 1,
+                            static_cast<hipStream_t>(stream), out_hi, out_lo);
 }

@@ -432,8 +432,19 @@ int avi_gemm_dma_launch(const AviGemm& g, hipStream_t s);
 // gemm_pp.hip: 256x256 ping-pong kernel (two wave groups alternate memory and matrix sections)
 bool avi_gemm_pp_ok(const AviGemm& g);
 int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s);
+// gemm_pp192.hip: the same schedule on 128x192 tiles (transformer projections: M = 8000, N = 768 / 2304 / 3072)
+bool avi_gemm_pp192_ok(const AviGemm& g);
+int avi_gemm_pp192_launch(const AviGemm& g, hipStream_t s);
 
-static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3: double-buffered v2 kernel for fp32 A; =2: see below
+// Fraction of the launched tile area that is useful work when `cus` workgroups run per round (1 per CU), times a
+// per-tile efficiency (the smaller tile moves more LDS-DMA pieces per MFMA): picks the tile shape for a problem.
+static double tile_score(const AviGemm& g, int bm, int bn, double eff) {
+    const long long tiles = (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch;
+    const long long rounds = (tiles + 255) / 256;
+    return eff * (double)g.M * g.N * g.batch / ((double)rounds * 256 * bm * bn);
+}
+
+static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3: double-buffered v2 kernel for fp32 A; 2/4/5: see below
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("AVI_GEMM_KERNEL");
@@ -468,8 +479,15 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     if (prec != AVI_PREC_BF16 && prec != AVI_PREC_BF16X3) return AVI_EINVAL;
     if ((g.scale == nullptr) != (g.shift == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (planes) {   // AVI_GEMM_KERNEL=2 keeps the one-phase LDS-DMA kernel (A/B experiments)
-        if (gemm_kernel_choice() != 2 && avi_gemm_pp_ok(g)) return avi_gemm_pp_launch(g, s);
+    if (planes) {   // AVI_GEMM_KERNEL=2 keeps the one-phase LDS-DMA kernel, 4 / 5 force one ping-pong tile shape
+        const int choice = gemm_kernel_choice();
+        const bool ok256 = avi_gemm_pp_ok(g) && choice != 2 && choice != 5;
+        const bool ok192 = avi_gemm_pp192_ok(g) && choice != 2 && choice != 4;
+        if (ok256 && ok192)
+            return tile_score(g, 128, 192, 0.85) > tile_score(g, 256, 256, 1.0) ? avi_gemm_pp192_launch(g, s)
+                                                                                   : avi_gemm_pp_launch(g, s);
+        if (ok256) return avi_gemm_pp_launch(g, s);
+        if (ok192) return avi_gemm_pp192_launch(g, s);
         return avi_gemm_dma_launch(g, s);
     }
     const bool narrow = g.N <= 64;

@@ -1,0 +1,299 @@
+// 128 x 192 tile variant of the ping-pong GEMM (gemm_pp.hip) for the transformer projections of the audio encoder
+// (M = 8000 rows, N = 768 / 2304 / 3072: 63 x 4 / 12 / 16 tiles = 0.98 / 2.95 / 3.94 rounds of 256 CUs, where the
+// 256 x 256 tile gives 0.38 / 1.13 / 1.5).  Same contract and the same idea - the two waves of a SIMD alternate between
+// a memory section (counted vmcnt wait, LDS-DMA pieces, ds_read_b128 fragments) and a matrix section, group B
+// (wr = 1) running one s_barrier behind group A - with the schedule re-derived for the smaller tile:
+//
+//   * 8 waves = 2 (m) x 4 (n), 64 x 48 outputs each (4 x 3 accumulator tiles);
+//   * a K tile is staged as THREE areas X0 | X1 | W (64 + 64 + 192 rows of 128 B = 40 KiB), three stages (120 KiB);
+//   * two phases per K tile T (phase p = 2T + h, stage T % 3):
+//       h = 0   reads X0(T), W(T)     multiplies m-tiles 0,1 x n-tiles 0..2 (18 MFMA in bf16x3)   issues W(T+2)
+//       h = 1   reads X1(T)           multiplies m-tiles 2,3 (W fragments stay in registers)      issues X0(T+2), X1(T+2)
+//     WAR  an area is restaged >= 2 phases after its last read (W(T-1), X0(T-1) read in phase 2T-2, X1(T-1) in 2T-1;
+//          restaged in phases 2T and 2T+1);
+//     RAW  the wait for an area read in phase q sits at the top of phase q-1, before that phase's own issues:
+//          odd phases wait `vmcnt(4)` (X0, W of the next K tile have landed; X1 of it and the 3 W pieces of the tile
+//          after may fly), even phases `vmcnt(5)` (X1 of this K tile; 3 W + 2 X pieces may fly).
+//   * the K loop is unrolled by three K tiles so every LDS offset is an immediate (K tiles must come in threes:
+//     K % 96 == 0 in bf16x3, K % 192 == 0 in bf16); past the end of K the issue slots reload the last K tile.
+//   * epilogue: per-wave LDS transposition (64 rows x 48 columns, row stride 208 B), then 16-B stores along rows.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 192, NTHR = 512;
+constexpr int X_BYTES = 64 * 128, W_BYTES = 192 * 128;
+constexpr int STAGE_BYTES = 2 * X_BYTES + W_BYTES;    // 40 KiB
+constexpr int NSTAGE = 3;
+constexpr int EP_STRIDE = 208;                        // epilogue slab: 48 fp32 + 16 B pad per row
+constexpr int EP_SLAB = 64 * EP_STRIDE;
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;      // 120 KiB (>= 8 epilogue slabs = 104 KiB)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NS>
+__global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = tilesM * tilesN;
+    int t = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int zo = z / g.z_inner, zi = z - zo * g.z_inner;
+    const uint16_t* __restrict__ Ahi = g.Ahi + zo * g.sAo + zi * g.sAi;
+    const uint16_t* __restrict__ Alo = (NS == 2) ? g.Alo + zo * g.sAo + zi * g.sAi : Ahi;
+    const uint16_t* __restrict__ Whi = g.Whi + zo * g.sWo + zi * g.sWi;
+    const uint16_t* __restrict__ Wlo = (NS == 2) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
+
+    // ---- LDS-DMA source pointers (1 KiB pieces = 8 rows x 128 B; lane -> row 8 piece + lane/8, source chunk
+    //      c = lane%8 ^ (row&7)).  X0 / X1: piece = wave (64 rows: wave-row R/32 owns rows R%32 of its m-half);
+    //      W: pieces wave, wave + 8, wave + 16 (192 rows in column order).
+    constexpr int KB = NS == 2 ? 64 : 128;   // bytes one K tile advances along a row of a plane
+    const long long ldw = g.ldw ? g.ldw : g.K;
+    const char* xsrc[2];
+    const char* wsrc[3];
+    {
+        const int R = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (R & 7);
+        const int off = NS == 2 ? (c & 3) * 16 : c * 16;
+        const uint16_t* base = (NS == 2 && c >= 4) ? Alo : Ahi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + (R >> 5) * 64 + h * 32 + (R & 31);
+            m = m < g.M ? m : g.M - 1;
+            xsrc[h] = reinterpret_cast<const char*>(base + (long long)m * g.lda) + off;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int R = (wave + 8 * i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (R & 7);
+        const int off = NS == 2 ? (c & 3) * 16 : c * 16;
+        const uint16_t* base = (NS == 2 && c >= 4) ? Wlo : Whi;
+        int n = n0 + R;
+        n = n < g.N ? n : g.N - 1;
+        wsrc[i] = reinterpret_cast<const char*>(base + n * ldw) + off;
+    }
+    const int nk = g.K / (NS == 2 ? 32 : 64);   // multiple of 3 (checked by the launcher)
+
+    auto issue_w = [&](int T, int stage) __attribute__((always_inline)) {
+        const long long kofs = (long long)(T < nk ? T : nk - 1) * KB;
+        char* dst = smem + stage * STAGE_BYTES + 2 * X_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(wsrc[i] + kofs, dst + i * 8 * 1024);
+    };
+    auto issue_x = [&](int T, int stage) __attribute__((always_inline)) {
+        const long long kofs = (long long)(T < nk ? T : nk - 1) * KB;
+        char* dst = smem + stage * STAGE_BYTES + wave * 1024;
+        glds16(xsrc[0] + kofs, dst);
+        glds16(xsrc[1] + kofs, dst + X_BYTES);
+    };
+
+    // ---- fragment addresses: lane (fr, fq) reads row (16-row tile base) + fr, chunks fq and 4 + fq
+    const int fr = lane & 15, fq = lane >> 4;
+    const int pos = (fq ^ (fr & 7)) << 4;
+    const int xoff = (wr * 32 + fr) * 128 + pos;                   // + stage, + h * X_BYTES, + bl * 2048
+    const int woff = 2 * X_BYTES + (wc * 48 + fr) * 128 + pos;     // + stage, + a * 2048
+    const char* xhi_p = smem + xoff;
+    const char* xlo_p = smem + (xoff ^ 64);
+    const char* whi_p = smem + woff;
+    const char* wlo_p = smem + (woff ^ 64);
+
+    bf16x8 xh[2], xl[2], wh[3], wl[3];
+    auto read_x = [&](int stage, int h) __attribute__((always_inline)) {
+        const int o = stage * STAGE_BYTES + h * X_BYTES;
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+            xh[bl] = *reinterpret_cast<const bf16x8*>(xhi_p + o + bl * 2048);
+            xl[bl] = *reinterpret_cast<const bf16x8*>(xlo_p + o + bl * 2048);
+        }
+    };
+    auto read_w = [&](int stage) __attribute__((always_inline)) {
+        const int o = stage * STAGE_BYTES;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            wh[a] = *reinterpret_cast<const bf16x8*>(whi_p + o + a * 2048);
+            wl[a] = *reinterpret_cast<const bf16x8*>(wlo_p + o + a * 2048);
+        }
+    };
+
+    f32x4 acc[3][4];   // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto multiply = [&](int mh) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl) {
+                f32x4 c = acc[a][mh * 2 + bl];
+                if (NS == 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[a], xh[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xl[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xh[bl], c, 0, 0, 0);
+                } else {   // "hi"/"lo" positions are k 0..31 / 32..63 of the 64-wide K tile
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xh[bl], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[a], xl[bl], c, 0, 0, 0);
+                }
+                acc[a][mh * 2 + bl] = c;
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: what the steady state has issued before phase 0 (10 pieces per wave)
+    issue_w(0, 0);
+    issue_x(0, 0);
+    issue_w(1, 1);
+    issue_x(1, 1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // W(0), X0(0), X1(0) have landed
+    bar();
+    if (wr == 1) bar();                                  // group B runs one barrier behind group A
+
+    for (int T = 0; T < nk; T += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                    // K tile T + u in stage u
+            const int Tu = T + u;
+            const int s2 = u == 0 ? 2 : u - 1;           // stage of K tile Tu + 2
+            // even phase
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            issue_w(Tu + 2, s2);
+            read_x(u, 0);
+            read_w(u);
+            bar();
+            multiply(0);
+            bar();
+            // odd phase
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            issue_x(Tu + 2, s2);
+            read_x(u, 1);
+            bar();
+            multiply(1);
+            bar();
+        }
+    }
+    if (wr == 0) bar();                                  // group A catches up: equal barrier counts
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();                                               // every wave's tail DMA has landed: the stages are dead
+
+    // ---- epilogue (same contract as gemm.hip) through a per-wave LDS slab: 64 rows x 48 columns
+    float* __restrict__ C = g.C ? g.C + zo * g.sCo + zi * g.sCi : nullptr;
+    uint16_t* __restrict__ Chi = g.Chi ? g.Chi + zo * g.sCo + zi * g.sCi : nullptr;
+    uint16_t* __restrict__ Clo = g.Chi ? g.Clo + zo * g.sCo + zi * g.sCi : nullptr;
+    const float* __restrict__ bias = g.bias ? g.bias + zo * g.sBo + zi * g.sBi : nullptr;
+    const float* __restrict__ R = g.R ? g.R + zo * g.sRo + zi * g.sRi : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (!R || (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0))) &&
+                        (!Chi || (((reinterpret_cast<uintptr_t>(Chi) | reinterpret_cast<uintptr_t>(Clo)) & 7) == 0));
+    char* slab = smem + wave * EP_SLAB;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            *reinterpret_cast<f32x4*>(slab + (b * 16 + fr) * EP_STRIDE + (a * 16 + fq * 4) * 4) = acc[a][b];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, other lanes' rows
+    // 64 rows x 12 float4: item i = lane + 64 it -> row i / 12, columns 4 (i % 12) .. +3
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int i = lane + 64 * it;
+        const int row = i / 12, c4 = i - row * 12;
+        const int m = m0 + wr * 64 + row, n = n0 + wc * 48 + c4 * 4;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(slab + row * EP_STRIDE + c4 * 16);
+        if (m >= g.M || n >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = r0[j] + ((bias && n + j < g.N) ? bias[n + j] : 0.f);
+        if (g.act == AVI_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = avi_gelu(v[j]);
+        } else if (g.act != AVI_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = avi_act(v[j], g.act);
+        }
+        if (g.scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < g.N) v[j] = v[j] * g.scale[n + j] + g.shift[n + j];
+        }
+        if (vec_ok && n + 3 < g.N) {
+            if (R) {
+                const float4 q = *reinterpret_cast<const float4*>(R + (long long)m * g.ldr + n);
+                v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+            }
+            if (C) *reinterpret_cast<float4*>(C + (long long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (Chi) {
+                uint32_t h[2], l[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
+                    const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
+                    h[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+                    l[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                }
+                const long long o = (long long)m * g.ldc + n;
+                *reinterpret_cast<uint2*>(Chi + o) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2*>(Clo + o) = make_uint2(l[0], l[1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < g.N) {
+                    const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
+                    if (C) C[(long long)m * g.ldc + n + j] = y;
+                    if (Chi) {
+                        const __bf16 hb = (__bf16)y;
+                        Chi[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, hb);
+                        Clo[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, (__bf16)(y - (float)hb));
+                    }
+                }
+        }
+    }
+}
+
+template <int NS>
+int launch(const AviGemm& g, hipStream_t s) {
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp192_kernel<NS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_pp192_kernel<NS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+                       tilesN);
+    return avi_launch_status();
+}
+
+}  // namespace
+
+// true when the 128 x 192 kernel can take the problem (K tiles come in threes)
+bool avi_gemm_pp192_ok(const AviGemm& g) {
+    const int kt = (g.prec & 0xff) == AVI_PREC_BF16X3 ? 32 : 64;
+    return g.Ahi && g.K % (3 * kt) == 0;
+}
+
+int avi_gemm_pp192_launch(const AviGemm& g, hipStream_t s) {
+    return (g.prec & 0xff) == AVI_PREC_BF16X3 ? launch<2>(g, s) : launch<1>(g, s);
+}

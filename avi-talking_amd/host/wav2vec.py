@@ -38,10 +38,11 @@ class Wav2Vec2Model:
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
         # Activation format.  Conv stack: bf16 hi/lo planes feeding the 256x256 ping-pong GEMM (gemm_pp.hip), each
         # layer's epilogue emitting the next layer's planes (AVI_W2V_PLANES=0: fp32 activations + gemm.hip).
-        # Transformer: fp32 activations by default - at M = 8000 the 256x256 tiles quantise badly (288 tiles on
-        # 256 CUs for qkv) and gemm.hip's 128x128 tiles win; AVI_W2V_TF_PLANES=1 selects planes there too.
+        # Transformer: planes as well - LayerNorm, attention and ffn1 emit them, the four projections run on the
+        # 128x192 ping-pong GEMM (gemm_pp192.hip: 63 x N/192 tiles fill 256 CUs to 98 % at M = 8000)
+        # (AVI_W2V_TF_PLANES=0: fp32 activations + gemm.hip's 128x128 tiles).
         self.use_planes = os.environ.get("AVI_W2V_PLANES", "1") == "1"
-        self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "0") == "1"
+        self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "1") == "1"
         # optional callable run on the launch stream between conv layer 0 and the chip-filling conv GEMMs (the
         # sampling pipeline makes the main stream wait there for the aligner network of the prior branch)
         self.before_conv_stack = None
@@ -144,13 +145,13 @@ class Wav2Vec2Model:
         # LayerNorm outputs feed a big GEMM (qkv / ffn1) AND the residual: emitted as split planes + fp32
         h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h)
         d = HIDDEN // HEADS
-        for ly in self.layers:
-            qkv = ops.linear_planes(hp_, ly.qkv, prec=self.prec)                      # (B,T,2304), LDS-DMA GEMM
-            att = ops.attention_d64(qkv, HEADS, d ** -0.5)                           # MFMA, bf16x3 operands
-            h = ops.linear(att, ly.out, residual=h, prec=self.prec)
+        for ly in self.layers:   # every projection on the 128x192 ping-pong GEMM, every activation split once
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=self.prec)                      # (B,T,2304) fp32
+            att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5)                    # planes
+            h = ops.linear_planes(att, ly.out, residual=h, prec=self.prec)
             h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h)
-            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=self.prec)
-            h = ops.linear(f, ly.ff2, residual=h, prec=self.prec)
+            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=self.prec, out_planes=True)
+            h = ops.linear_planes(f, ly.ff2, residual=h, prec=self.prec)
             h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h)
         return h
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
+    "avi_attention_d64_planes": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],

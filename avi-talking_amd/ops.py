@@ -251,6 +251,18 @@ def attention_d64(qkv, H, scale, out=None):
     return out
 
 
+def attention_d64_planes(qkv, H, scale):
+    """Head-dim-64 attention whose result is written as split planes (operand of the out_proj GEMM)."""
+    qkv = _f32c(qkv, "qkv")
+    B, T, ld = qkv.shape
+    if ld != 3 * H * 64:
+        raise ValueError(f"attention_d64_planes: last dim {ld} != 3*H*64")
+    out = Planes((B, T, H * 64), qkv.device)
+    L.check(L.load().avi_attention_d64_planes(qkv.data_ptr(), B, H, T, ld, scale, None, out.hi.data_ptr(),
+                                              out.lo.data_ptr(), H * 64, L.stream_ptr()), "avi_attention_d64_planes")
+    return out
+
+
 # ------------------------------------------------------------------ split-plane activations (x = hi + lo, bf16 each)
 class Planes:
     """An activation stored as two bf16 planes (int16 storage), the operand format of the LDS-DMA GEMM."""
@@ -296,21 +308,26 @@ def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_
     return out
 
 
-def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None):
-    """fp32 out[..., N] = act(x @ W^T + b) + residual with x given as split planes."""
+def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None, out_planes=False):
+    """out[..., N] = act(x @ W^T + b) + residual with x given as split planes; the result is fp32, or split planes
+    too (``out_planes=True``: a ``Planes`` for the next GEMM)."""
     K = xp.shape[-1]
     if K != pw.K or pw.N <= 64:
         raise ValueError("linear_planes: shape mismatch / N too narrow for the LDS-DMA kernel")
     M = 1
     for d in xp.shape[:-1]:
         M *= d
-    if out is None:
-        out = torch.empty(xp.shape[:-1] + (pw.N,), dtype=torch.float32, device=xp.hi.device)
     if residual is not None and _f32c(residual, "residual").numel() != M * pw.N:
         raise ValueError("linear_planes: bad residual shape")
+    if out_planes:
+        out = Planes(tuple(xp.shape[:-1]) + (pw.N,), xp.hi.device)
+        c_args = dict(Chi=out.hi.data_ptr(), Clo=out.lo.data_ptr())
+    else:
+        if out is None:
+            out = torch.empty(tuple(xp.shape[:-1]) + (pw.N,), dtype=torch.float32, device=xp.hi.device)
+        c_args = dict(C_=out.data_ptr())
     gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
-             C_=out.data_ptr(), ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act,
-             prec=prec)
+             ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act, prec=prec, **c_args)
     return out
 
 

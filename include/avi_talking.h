@@ -157,6 +157,10 @@ int avi_attention(const float* q, const float* k, const float* v, float* out, in
  * scratch >= 6 * B*H*Tp*64 bf16 values (Tp = T rounded up to 64), 16-byte aligned. */
 int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, float scale, float* out, int ldo,
                       uint16_t* scratch, void* stream);
+/* Same attention, result as split bf16 planes out_hi/out_lo [B][T][ldo] (x = hi + lo; `out` fp32 optional, may be NULL):
+ * the activation format of the LDS-DMA GEMMs, so encoder.layers.*.attention.out_proj reads it without conversion. */
+int avi_attention_d64_planes(const float* qkv, int B, int H, int T, int ld, float scale, float* out,
+                             uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion prior.  Replaces VersatileDiffusionPriorNetwork.forward (models/diffusion_prior.py:223-313),

@@ -29,7 +29,7 @@ def test_wav2vec2_parity(gpu, B, N, frame_num):
     assert e_fast < 0.15         # single-pass bf16: ~4e-3 relative per GEMM through 20 layers
 
 
-@pytest.mark.parametrize("conv_planes,tf_planes", [("0", "0"), ("1", "1")])
+@pytest.mark.parametrize("conv_planes,tf_planes", [("0", "0"), ("1", "0"), ("0", "1")])
 def test_wav2vec2_activation_formats(gpu, monkeypatch, conv_planes, tf_planes):
     """The non-default activation formats (fp32 conv stack / split-plane transformer) give the same result."""
     from avi_talking_amd.weights import make_wav2vec2_weights
