@@ -29,7 +29,7 @@ def _stale(obj, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "avi_talking.h"))
     objs, procs = [], []
     for src in sources():

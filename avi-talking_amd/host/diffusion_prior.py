@@ -15,6 +15,8 @@ out of scope: callers pass ``voxel`` = mean CLIP token embedding (B,768) as the 
 import math
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from .. import lib as L
@@ -181,21 +183,30 @@ class VersatileDiffusionPriorNetwork:
         pl = L.AviPriorPlanes()
         self._packs = []
 
-        def planes(mat):
-            pw = ops.PackedWeight(mat.to(self.device))                 # [N][K] bf16 hi / lo
+        def planes(mat, fp16=False):
             N, K = mat.shape
             frag = lambda t: (t[:N].view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous())
+            if fp16:                                                   # one plane of fp16 values, no lo part
+                hi = frag(mat.to(self.device, torch.float16).contiguous().view(torch.int16))
+                self._packs.append(hi)
+                return hi.data_ptr(), None
+            pw = ops.PackedWeight(mat.to(self.device))                 # [N][K] bf16 hi / lo
             hi, lo = frag(pw.hi), frag(pw.lo)                          # [N/16][K/32][g][c][8] = lane (c + 16 g)
             self._packs += [hi, lo]
             return hi.data_ptr(), lo.data_ptr()
+
+        # Feed-forward matrices (57 % of the bytes every DDPM step streams through each CU) as one fp16 plane: their
+        # rounding moves the final coefficients by 2e-5, a tenth of what the attention matrices' would (oracle
+        # sensitivity study in DESIGN.md); AVI_PRIOR_FF_FP16=0 keeps the 3-term bf16 split everywhere.
+        self.ff_fp16 = os.environ.get("AVI_PRIOR_FF_FP16", "1") == "1"
 
         for l in range(depth):
             a, f = f"{c}layers.{l}.0.", f"{c}layers.{l}.1."
             lp = pl.layer[l]
             lp.qkv_hi, lp.qkv_lo = planes(torch.cat([w[a + "to_q.weight"], w[a + "to_kv.weight"]], 0))
             lp.out_hi, lp.out_lo = planes(w[a + "to_out.0.weight"])
-            lp.w1_hi, lp.w1_lo = planes(w[f + "1.weight"])
-            lp.w2_hi, lp.w2_lo = planes(w[f + "5.weight"])
+            lp.w1_hi, lp.w1_lo = planes(w[f + "1.weight"], self.ff_fp16)
+            lp.w2_hi, lp.w2_lo = planes(w[f + "5.weight"], self.ff_fp16)
         pl.proj_hi, pl.proj_lo = planes(w[c + "project_out.weight"])
         self.planes = pl
         cw.coef1 = dev(sched["posterior_mean_coef1"])

@@ -204,6 +204,8 @@ typedef struct AviPriorLayerPlanes {
     const uint16_t *out_hi, *out_lo;   /* [128][512]  to_out.0.weight */
     const uint16_t *w1_hi, *w1_lo;     /* [1024][128] layers.{l}.1.1.weight */
     const uint16_t *w2_hi, *w2_lo;     /* [128][512]  layers.{l}.1.5.weight */
+    /* w1_lo == w2_lo == NULL: w1_hi / w2_hi hold ONE plane of IEEE fp16 values (same fragment order); the kernel then
+     * splits the activation into fp16 hi + lo and spends two MFMAs per product (half the streamed bytes). */
 } AviPriorLayerPlanes;
 typedef struct AviPriorPlanes {
     AviPriorLayerPlanes layer[AVI_PRIOR_MAX_DEPTH];

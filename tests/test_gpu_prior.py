@@ -58,10 +58,13 @@ def test_prior_step_parity(gpu, pw):
     assert e1 < 1e-4 and e2 < 1e-4
 
 
-@pytest.mark.parametrize("B,spg", [(3, 0), (32, 0), (3, 4), (32, 4), (7, 5), (6, 1)])
-def test_ddpm_sampling_parity(gpu, pw, B, spg):
+@pytest.mark.parametrize("B,spg,ff16", [(3, 0, "1"), (32, 0, "1"), (3, 4, "1"), (32, 4, "1"), (7, 5, "1"), (6, 1, "1"),
+                                        (6, 1, "0"), (7, 3, "0")])
+def test_ddpm_sampling_parity(gpu, pw, B, spg, ff16, monkeypatch):
+    """ff16 = "1": feed-forward matrices streamed as one fp16 plane (default); "0": 3-term bf16 split everywhere."""
     from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior
     from oracle import prior as OP
+    monkeypatch.setenv("AVI_PRIOR_FF_FP16", ff16)
     g = torch.Generator().manual_seed(14)
     te = torch.randn(B, 1, 128, generator=g)
     noise = torch.randn(101, B, 1, 128, generator=torch.Generator().manual_seed(0))
@@ -71,7 +74,8 @@ def test_ddpm_sampling_parity(gpu, pw, B, spg):
     idx = sorted({0, 1, B // 2, B - 1})   # the CPU oracle loop is slow; samples are independent
     ref = OP.p_sample_loop(pw, te[idx], noise[:, idx])
     err = (out[idx] - ref).abs().max().item()
-    print(f"DDPM 100-step (samples_per_group={spg}) err {err:.2e}, scale {ref.std():.3f}")
+    print(f"DDPM 100-step (samples_per_group={spg}, ff fp16={ff16}) err {err:.2e}, scale {ref.std():.3f}")
     assert out.shape == (B, 1, 128)
     assert torch.isfinite(out).all()
-    assert err < 1e-3 and err < (1e-5 if spg == 0 else 2e-4)
+    # vector kernel (spg 0): fp32; matrix-core kernel: 3-term bf16 (2e-5) or fp16 feed-forward weights (1e-4)
+    assert err < 1e-3 and err < (1e-5 if spg == 0 else 2e-5 if ff16 == "0" else 1e-4)
