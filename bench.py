@@ -205,7 +205,16 @@ def gemm_family(kw):
     """Which kernel avi_gemm dispatches a launch to (mirrors csrc/gemm.hip avi_gemm)."""
     if kw.get("Ahi"):
         kt = 32 if (kw.get("prec", 3) & 0xff) == 3 else 64
-        return "gemm_pp_kernel" if kw["K"] % (2 * kt) == 0 else "gemm_dma_kernel"
+        M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
+
+        def score(bm, bn, eff):                      # csrc/gemm.hip tile_score
+            tiles = -(-M // bm) * -(-N // bn) * batch
+            return eff * M * N * batch / (-(-tiles // 256) * 256 * bm * bn)
+
+        ok256, ok192 = K % (2 * kt) == 0, K % (3 * kt) == 0
+        if ok256 and ok192:
+            return "gemm_pp192_kernel" if score(128, 192, 0.85) > score(256, 256, 1.0) else "gemm_pp_kernel"
+        return "gemm_pp_kernel" if ok256 else "gemm_pp192_kernel" if ok192 else "gemm_dma_kernel"
     return "gemm_kernel<128>" if kw["N"] > 64 else "gemm_kernel<64>"
 
 
