@@ -7,27 +7,26 @@
 // waves sit in their memory section (one LDS-DMA piece costs 100-185 issue cycles next to ds_reads) at the same time
 // and the matrix pipe idles ~55 % of the cycles.  Here the two waves of a SIMD ALTERNATE:
 //
-//   * one workgroup of 8 waves (2 along m x 4 along n, 128 x 64 outputs each) per CU, 128 KiB of LDS;
-//   * the 4 waves with wr = 1 ("group B") run ONE s_barrier behind the 4 waves with wr = 0 ("group A").  A phase is
-//       [memory section: counted vmcnt wait, 2 LDS-DMA pieces, 4 or 8 ds_read_b128]  s_barrier
-//       [matrix section: the MFMAs of one quadrant of the wave's tile (24 in bf16x3, 16 in bf16)]  s_barrier
-//     so in every barrier interval one wave of each SIMD multiplies while the other one loads;
+//   * one workgroup of 8 waves (2 along m x 4 along n, 128 x 64 outputs each) per CU, 128 KiB of LDS for the stages;
+//   * a phase = [memory section: counted vmcnt wait, 2 LDS-DMA pieces, 0..12 ds_read_b128] + [matrix section: the MFMAs
+//     of one quadrant of the wave's tile (24 in bf16x3, 16 in bf16)] + ONE s_barrier.  The 4 waves with wr = 0
+//     ("group A") run memory -> matrix inside a barrier interval, the 4 with wr = 1 ("group B") matrix -> memory (their
+//     fragments were read in the previous interval), so on every SIMD one wave multiplies while the other loads;
 //   * a K tile (32 k in bf16x3: rows of [hi 64 B | lo 64 B]; 64 k in bf16: rows of 128 B) is staged as FOUR half
 //     tiles (X0 X1 W0 W1: the rows the quadrant m-half / n-half of every wave needs), two stages, one half tile per
-//     phase, each issued SIX phases before its first read.  Hazards, in phases (cdna_hip_programming.md section 5,
-//     "Read a staged buffer one phase after the wait that retires it"):
-//       RAW  the wait for a half tile read in phase q sits at the top of phase q-1 (one barrier more than a
-//            lock-step kernel needs, because group B waits one barrier later than group A reads);
-//       WAR  a slot is restaged >= 2 phases after its last ds_read (group B's read retires in its matrix section,
-//            one barrier before group A's restage).
+//     phase, each issued FIVE or six phases before its first read.  Hazards, in phases (cdna_hip_programming.md
+//     section 5, "Read a staged buffer one phase after the wait that retires it"):
+//       RAW  the wait for a half tile read in phase q sits at the top of the memory section of phase q-1 (group B's
+//            wait and group A's read are then separated by the barrier of phase q-1);
+//       WAR  a slot is restaged >= 2 phases after its last ds_read (group B's read of phase q retires before its
+//            matrix section in interval q+1, i.e. before the barrier group A passes on its way to phase q+2).
 //     Per K tile T (stage s = T & 1):   reads            matrix quadrant   LDS-DMA issue
-//       P1                               X0(T)            (m0, n0)          X1(T+1) -> stage s^1
-//       P2                               W1(T)            (m0, n1)          W0(T+2) -> stage s
+//       P1                               X0(T), W0(T)     (m0, n0)          W1(T+1) -> stage s^1
+//       P2                               W1(T)            (m0, n1)          X1(T+1) -> stage s^1
 //       P3                               X1(T)            (m1, n1)          X0(T+2) -> stage s
-//       P4                               W0(T+1)          (m1, n0)          W1(T+2) -> stage s
-//     (W0 lives in registers across the K tile, double-buffered over two K tiles: the loop is unrolled by two.)
-//     Every phase starts with `s_waitcnt vmcnt(8)`: the 4 half tiles (8 pieces per wave) issued after the one the
-//     NEXT phase reads may stay in flight - 64-80 KiB per CU is always on its way.
+//       P4                               -                (m1, n0)          W0(T+2) -> stage s
+//     Every memory section starts with `s_waitcnt vmcnt(6)`: the 3 half tiles (6 pieces per wave) issued after the
+//     one the NEXT phase reads may stay in flight - 48-64 KiB per CU is always on its way.
 //   * past the end of K the issue slots load the last K tile again into slots nobody reads any more, which keeps
 //     the vmcnt arithmetic uniform (3 % extra L2 reads at K = 1536).
 //   * LDS image and fragment addressing as in gemm_dma.hip: lane-linear LDS-DMA with the bank swizzle applied on the
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
         __builtin_amdgcn_s_setprio(0);
     };
     auto mem_top = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     };
     auto bar = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
@@ -178,59 +177,84 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     st[0] = __builtin_amdgcn_s_memtime();
     st[4] = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- prologue: the 7 half tiles the steady-state schedule has in flight before phase 1 of K tile 0
-    issue(KW0, 0, 0);
+    // ---- prologue: the 6 half tiles the steady-state schedule has in flight before phase 1 of K tile 0
     issue(KX0, 0, 0);
+    issue(KW0, 0, 0);
     issue(KW1, 0, 0);
     issue(KX1, 0, 0);
-    issue(KW0, 1, 1);
     issue(KX0, 1, 1);
-    issue(KW1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W0(0), X0(0), W1(0) have landed
+    issue(KW0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // X0(0), W0(0), W1(0) have landed
     bar();
-    bf16x8 w0h[2][2], w0l[2][2];                        // W0 fragments, double-buffered over two K tiles
-    read_w(0, 0, w0h[0], w0l[0]);
-    if (wr == 1) bar();                                 // group B runs one barrier behind group A
 
 #ifdef AVI_PP_STAMPS
     st[1] = __builtin_amdgcn_s_memtime();
 #endif
-    bf16x8 xh[4], xl[4], w1h[2], w1l[2];
-    for (int T = 0; T < nk; T += 2) {
+    // ONE barrier per phase.  Group A (wr = 0) runs  mem(p) ; mfma(p) ; barrier,  group B (wr = 1) runs
+    // mfma(p-1) ; mem(p) ; barrier : inside a barrier interval one wave of each SIMD is in its memory section while
+    // the other multiplies, then they swap.  In phases the hazards are those of the header: every ds_read of phase q
+    // has retired before the barrier that ends phase q+1 (WAR: restage >= 2 phases after the last read), and every
+    // wave's vmcnt wait for what phase q reads sits in phase q-1 (RAW).
+    bf16x8 xh[4], xl[4], w0h[2], w0l[2], w1h[2], w1l[2];
+    auto mem1 = [&](int Tu, int u) __attribute__((always_inline)) {
+        mem_top();
+        issue(KW1, Tu + 1, u ^ 1);
+        read_w(u, 0, w0h, w0l);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(u, 0, xh, xl);
+    };
+    auto mem2 = [&](int Tu, int u) __attribute__((always_inline)) {
+        mem_top();
+        issue(KX1, Tu + 1, u ^ 1);
+        read_w(u, 1, w1h, w1l);
+    };
+    auto mem3 = [&](int Tu, int u) __attribute__((always_inline)) {
+        mem_top();
+        issue(KX0, Tu + 2, u);
+        read_x(u, 1, xh, xl);
+    };
+    auto mem4 = [&](int Tu, int u) __attribute__((always_inline)) {
+        mem_top();
+        issue(KW0, Tu + 2, u);
+    };
+    if (wr == 0) {
+        for (int T = 0; T < nk; T += 2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                   // K tile T + u in stage u
-            const int Tu = T + u;
-            // P1
-            mem_top();
-            issue(KX1, Tu + 1, u ^ 1);
-            read_x(u, 0, xh, xl);
-            bar();
-            quadrant(0, 0, xh, xl, w0h[u], w0l[u]);
-            bar();
-            // P2
-            mem_top();
-            issue(KW0, Tu + 2, u);
-            read_w(u, 1, w1h, w1l);
-            bar();
-            quadrant(0, 1, xh, xl, w1h, w1l);
-            bar();
-            // P3
-            mem_top();
-            issue(KX0, Tu + 2, u);
-            read_x(u, 1, xh, xl);
-            bar();
-            quadrant(1, 1, xh, xl, w1h, w1l);
-            bar();
-            // P4
-            mem_top();
-            issue(KW1, Tu + 2, u);
-            read_w(u ^ 1, 0, w0h[u ^ 1], w0l[u ^ 1]);   // W0 of the next K tile
-            bar();
-            quadrant(1, 0, xh, xl, w0h[u], w0l[u]);
-            bar();
+            for (int u = 0; u < 2; ++u) {               // K tile T + u in stage u
+                mem1(T + u, u);
+                quadrant(0, 0, xh, xl, w0h, w0l);
+                bar();
+                mem2(T + u, u);
+                quadrant(0, 1, xh, xl, w1h, w1l);
+                bar();
+                mem3(T + u, u);
+                quadrant(1, 1, xh, xl, w1h, w1l);
+                bar();
+                mem4(T + u, u);
+                quadrant(1, 0, xh, xl, w0h, w0l);
+                bar();
+            }
+        }
+    } else {
+        mem1(0, 0);
+        for (int T = 0; T < nk; T += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                quadrant(0, 0, xh, xl, w0h, w0l);
+                mem2(T + u, u);
+                bar();
+                quadrant(0, 1, xh, xl, w1h, w1l);
+                mem3(T + u, u);
+                bar();
+                quadrant(1, 1, xh, xl, w1h, w1l);
+                mem4(T + u, u);
+                bar();
+                quadrant(1, 0, xh, xl, w0h, w0l);
+                mem1(T + u + 1, u ^ 1);                 // first phase of the next K tile (a dummy after the last)
+                bar();
+            }
         }
     }
-    if (wr == 0) bar();                                 // group A catches up: equal barrier counts
 
 #ifdef AVI_PP_STAMPS
     st[2] = __builtin_amdgcn_s_memtime();

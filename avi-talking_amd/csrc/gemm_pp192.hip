@@ -1,8 +1,9 @@
 // 128 x 192 tile variant of the ping-pong GEMM (gemm_pp.hip) for the transformer projections of the audio encoder
 // (M = 8000 rows, N = 768 / 2304 / 3072: 63 x 4 / 12 / 16 tiles = 0.98 / 2.95 / 3.94 rounds of 256 CUs, where the
 // 256 x 256 tile gives 0.38 / 1.13 / 1.5).  Same contract and the same idea - the two waves of a SIMD alternate between
-// a memory section (counted vmcnt wait, LDS-DMA pieces, ds_read_b128 fragments) and a matrix section, group B
-// (wr = 1) running one s_barrier behind group A - with the schedule re-derived for the smaller tile:
+// a memory section (counted vmcnt wait, LDS-DMA pieces, ds_read_b128 fragments) and a matrix section, one s_barrier
+// per phase, group A memory -> matrix and group B (wr = 1) matrix -> memory inside a barrier interval - with the
+// schedule re-derived for the smaller tile:
 //
 //   * 8 waves = 2 (m) x 4 (n), 64 x 48 outputs each (4 x 3 accumulator tiles);
 //   * a K tile is staged as THREE areas X0 | X1 | W (64 + 64 + 192 rows of 128 B = 40 KiB), three stages (120 KiB);
@@ -170,31 +171,46 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     issue_x(1, 1);
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // W(0), X0(0), X1(0) have landed
     bar();
-    if (wr == 1) bar();                                  // group B runs one barrier behind group A
-
-    for (int T = 0; T < nk; T += 3) {
+    // ONE barrier per phase: group A (wr = 0) runs memory -> matrix inside a barrier interval, group B matrix (on the
+    // fragments it read in the previous interval) -> memory, so the two waves of a SIMD alternate (gemm_pp.hip).
+    auto mem_even = [&](int Tu, int u) __attribute__((always_inline)) {   // K tile Tu in stage u
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        issue_w(Tu + 2, u == 0 ? 2 : u - 1);
+        read_w(u);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(u, 0);
+    };
+    auto mem_odd = [&](int Tu, int u) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        issue_x(Tu + 2, u == 0 ? 2 : u - 1);
+        read_x(u, 1);
+    };
+    if (wr == 0) {
+        for (int T = 0; T < nk; T += 3) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {                    // K tile T + u in stage u
-            const int Tu = T + u;
-            const int s2 = u == 0 ? 2 : u - 1;           // stage of K tile Tu + 2
-            // even phase
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            issue_w(Tu + 2, s2);
-            read_x(u, 0);
-            read_w(u);
-            bar();
-            multiply(0);
-            bar();
-            // odd phase
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            issue_x(Tu + 2, s2);
-            read_x(u, 1);
-            bar();
-            multiply(1);
-            bar();
+            for (int u = 0; u < 3; ++u) {
+                mem_even(T + u, u);
+                multiply(0);
+                bar();
+                mem_odd(T + u, u);
+                multiply(1);
+                bar();
+            }
+        }
+    } else {
+        mem_even(0, 0);
+        for (int T = 0; T < nk; T += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                multiply(0);
+                mem_odd(T + u, u);
+                bar();
+                multiply(1);
+                mem_even(T + u + 1, u == 2 ? 0 : u + 1);   // even phase of the next K tile (a dummy after the last)
+                bar();
+            }
         }
     }
-    if (wr == 0) bar();                                  // group A catches up: equal barrier counts
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();                                               // every wave's tail DMA has landed: the stages are dead
 
