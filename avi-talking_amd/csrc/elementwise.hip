@@ -24,6 +24,16 @@ __device__ __forceinline__ float4 join4_load(const uint16_t* hi, const uint16_t*
                        f(h.y << 16) + f(l.y << 16), f(h.y & 0xffff0000u) + f(l.y & 0xffff0000u));
 }
 
+// Accumulators are zeroed by a kernel of this library rather than hipMemsetAsync (one dependency less on the runtime's
+// blit path inside captured graphs).
+__global__ void zero_doubles_kernel(double* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+static inline void zero_doubles(double* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(zero_doubles_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+
 // ------------------------------------------------------------------ audio zero-mean / unit-var
 // stats[2*s + {0,1}] = sum, sum of squares (double) of clip s (s = 0 when joint).
 template <bool I16>
@@ -458,7 +468,7 @@ extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, 
                                    double* stats, void* stream) {
     if (!pcm || !out || !stats || B <= 0 || N <= 0) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s) != hipSuccess) return avi_launch_status();
+    zero_doubles(stats, 2 * B, s);
     dim3 grid(grid_for(N, 256, 64), B);
     if (is_int16) {
         hipLaunchKernelGGL(audio_stats_kernel<true>, grid, dim3(256), 0, s, pcm, N, joint, stats);
@@ -476,7 +486,7 @@ static int conv0_impl(const float* x, int B, int N, const float* w0, const float
     if ((y_hi == nullptr) != (y_lo == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T0 = (N - K0) / ST0 + 1;
-    if (hipMemsetAsync(moments, 0, sizeof(double) * NMOM * B, s) != hipSuccess) return avi_launch_status();
+    zero_doubles(moments, NMOM * B, s);
     hipLaunchKernelGGL(conv0_moments_kernel, dim3(grid_for(T0, 256, 32), B), dim3(256), 0, s, x, N, T0, moments);
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, w0, gamma, beta, T0, eps,
                        scale_shift);

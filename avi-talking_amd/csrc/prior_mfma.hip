@@ -8,10 +8,10 @@ int avi_prior_sample_batched_f16_launch(const AviPriorWeights* w, const AviPrior
                                         const float* noise, int B, int samples_per_group, float inv_scale, float* out,
                                         float* temb_scratch, hipStream_t s);
 
-extern "C" int avi_prior_sample_batched(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
-                                        const float* noise, int B, int samples_per_group, float inv_scale, float* out,
-                                        float* temb_scratch, void* stream) {
-    if (!w || !p || !text_embed || !noise || !out || !temb_scratch || B <= 0) return AVI_EINVAL;
+static int sample_batched_impl(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
+                               const float* noise, int B, int samples_per_group, float inv_scale, float* out,
+                               float* temb, bool temb_ready, void* stream) {
+    if (!w || !p || !text_embed || !noise || !out || !temb || B <= 0) return AVI_EINVAL;
     if (samples_per_group < 1 || samples_per_group > SMAX) return AVI_EINVAL;
     if (w->depth < 1 || w->depth > AVI_PRIOR_MAX_DEPTH || !p->proj_hi || !p->proj_lo) return AVI_EINVAL;
     for (int l = 0; l < w->depth; ++l) {
@@ -21,10 +21,28 @@ extern "C" int avi_prior_sample_batched(const AviPriorWeights* w, const AviPrior
         if ((P.w1_lo == nullptr) != (p->layer[0].w1_lo == nullptr)) return AVI_EINVAL;   // same format in every layer
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = avi_prior_time_table_launch(w, temb_scratch, s);
-    if (rc != AVI_OK) return rc;
+    if (!temb_ready) {
+        const int rc = avi_prior_time_table_launch(w, temb, s);
+        if (rc != AVI_OK) return rc;
+    }
     if (p->layer[0].w1_lo == nullptr)   // feed-forward matrices as one fp16 plane
-        return avi_prior_sample_batched_f16_launch(w, p, text_embed, noise, B, samples_per_group, inv_scale, out,
-                                                   temb_scratch, s);
-    return launch_prior_variant<false>(w, p, text_embed, noise, B, samples_per_group, inv_scale, out, temb_scratch, s);
+        return avi_prior_sample_batched_f16_launch(w, p, text_embed, noise, B, samples_per_group, inv_scale, out, temb, s);
+    return launch_prior_variant<false>(w, p, text_embed, noise, B, samples_per_group, inv_scale, out, temb, s);
+}
+
+extern "C" int avi_prior_sample_batched(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
+                                        const float* noise, int B, int samples_per_group, float inv_scale, float* out,
+                                        float* temb_scratch, void* stream) {
+    return sample_batched_impl(w, p, text_embed, noise, B, samples_per_group, inv_scale, out, temb_scratch, false, stream);
+}
+
+extern "C" int avi_prior_time_table(const AviPriorWeights* w, float* temb, void* stream) {
+    return avi_prior_time_table_launch(w, temb, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int avi_prior_sample_batched_tab(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
+                                            const float* noise, int B, int samples_per_group, float inv_scale,
+                                            float* out, const float* temb_table, void* stream) {
+    return sample_batched_impl(w, p, text_embed, noise, B, samples_per_group, inv_scale, out,
+                               const_cast<float*>(temb_table), true, stream);
 }

@@ -269,6 +269,17 @@ class InstructDiffusionPrior:
         v2c = BrainNetwork(state_dict, device=device, prec=prec)
         return cls(net, voxel2clip=v2c, timesteps=timesteps, device=device)
 
+    def time_table(self):
+        """(T, 128) time embeddings of every timestep (models/diffusion_prior.py:188-191,284), built on first use."""
+        if getattr(self, "_time_table", None) is None:
+            import ctypes as C
+            t = torch.empty((self.noise_scheduler.num_timesteps, DIM), dtype=torch.float32, device=self.device)
+            L.check(L.load().avi_prior_time_table(C.byref(self.net.cw), t.data_ptr(), L.stream_ptr()),
+                    "avi_prior_time_table")
+            torch.cuda.current_stream(self.device).synchronize()
+            self._time_table = t
+        return self._time_table
+
     def draw_noise(self, batch, generator=None):
         """The (T+1, B, 1, 128) noise sequence the reference draws call by call from
         ``torch.randn(..., generator=generator)`` (models/diffusion_prior.py:337,349-351)."""
@@ -295,17 +306,18 @@ class InstructDiffusionPrior:
             noise[0] = image_embed.reshape(B, DIM).to(self.device, torch.float32)
         te = text_cond["text_embed"].reshape(B, DIM).to(self.device, torch.float32).contiguous()
         out = torch.empty((B, DIM), dtype=torch.float32, device=self.device)
-        temb = torch.empty((T, DIM), dtype=torch.float32, device=self.device)
         import ctypes as C
         spg = self.samples_per_group if samples_per_group is None else samples_per_group
         if spg <= 0:     # one workgroup per sample, fp32 vector pipe (prior.hip)
+            temb = torch.empty((T, DIM), dtype=torch.float32, device=self.device)
             L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
                                               1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
                                               L.stream_ptr()), "avi_prior_sample")
-        else:            # up to 5 samples per workgroup on the matrix cores (prior_mfma.hip)
-            spg = min(spg, B)
-            L.check(L.load().avi_prior_sample_batched(C.byref(self.net.cw), C.byref(self.net.planes), te.data_ptr(),
-                                                      noise.data_ptr(), B, spg, 1.0 / self.image_embed_scale,
-                                                      out.data_ptr(), temb.data_ptr(), L.stream_ptr()),
-                    "avi_prior_sample_batched")
+        else:            # up to 5 samples per workgroup on the matrix cores (prior_mfma.hip), ONE launch: the time
+            spg = min(spg, B)      # embeddings of all steps are a constant of the weights, built once (time_table)
+            L.check(L.load().avi_prior_sample_batched_tab(C.byref(self.net.cw), C.byref(self.net.planes),
+                                                          te.data_ptr(), noise.data_ptr(), B, spg,
+                                                          1.0 / self.image_embed_scale, out.data_ptr(),
+                                                          self.time_table().data_ptr(), L.stream_ptr()),
+                    "avi_prior_sample_batched_tab")
         return out.view(*shape)

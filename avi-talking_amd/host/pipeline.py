@@ -23,9 +23,9 @@ class SamplingPipeline:
         self.device = torch.device(device)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
         self.prior = InstructDiffusionPrior.from_state_dict(prior_sd, device=device, prec=prec)
-        # high priority: the prior branch is the longer one and its small aligner GEMMs must not queue behind the
-        # chip-filling conv GEMMs of the audio branch
+        # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
         self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        self.prior.time_table()          # built once, outside any capture
         self._graph = None
         self._static = None
 
@@ -43,23 +43,21 @@ class SamplingPipeline:
         B, N = pcm.shape
         T = N // 640
         cur = torch.cuda.current_stream(self.device)
+        # 1. Aligner MLP on the launch stream, before anything else (0.25 ms: split-K launches that stream the 300 MB
+        #    of weights at HBM speed).  It must not run beside the audio branch: with kernels starting and finishing
+        #    on a second stream while conv layer 0 was writing its 2 GB output, rows at both ends of that output came
+        #    out wrong (1e-3 .. 1e0, eager and graph replay alike; serial runs and a single long-running kernel on the
+        #    second stream are bit-exact - scripts/diag_concurrency.py).  So the only work that overlaps the audio
+        #    branch is ONE launch: the 100-step sampler.
+        clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
+        # 2. fork: the sampler (32 workgroups for ~12 ms) on the side stream, the audio encoder on this one
         self.side.wait_stream(cur)
-        aligned = torch.cuda.Event()
         with torch.cuda.stream(self.side):
-            # aligner network first; its ten small launches would each queue ~0.1 ms for a CU behind the resident
-            # 256x256 GEMM workgroups of the conv stack (measured: 2.9 ms instead of 0.4 ms, all of it on the critical
-            # path of the prior branch), so the conv stack is held back until the aligner is done
-            clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
-            aligned.record(self.side)
             style = self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
                                              cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
                                              noise=noise)
-        audio_model = self.talking_head.audio_model
-        audio_model.before_conv_stack = lambda: cur.wait_event(aligned)
-        try:
-            sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
-        finally:
-            audio_model.before_conv_stack = None
+        sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
+        # 3. join
         cur.wait_stream(self.side)
         out = self.talking_head.head(sample["audio_feature"], style)
         out["style_emb"] = style

@@ -87,6 +87,8 @@ SIGNATURES = {
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
+    "avi_prior_sample_batched_tab": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
+    "avi_prior_time_table": [_vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -228,6 +228,13 @@ int avi_prior_sample(const AviPriorWeights* w, const float* text_embed, const fl
 int avi_prior_sample_batched(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
                              const float* noise, int B, int samples_per_group, float inv_scale, float* out,
                              float* temb_scratch, void* stream);
+/* The time embeddings of all timesteps, [timesteps][128] (to_time_embeds of models/diffusion_prior.py:188-191,284): a
+ * constant of the weights, so a caller may build it once ... */
+int avi_prior_time_table(const AviPriorWeights* w, float* temb, void* stream);
+/* ... and sample with it: ONE launch on `stream` (no table kernel in front of the sampler). */
+int avi_prior_sample_batched_tab(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
+                                 const float* noise, int B, int samples_per_group, float inv_scale, float* out,
+                                 const float* temb_table, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FaceFormer-style autoregressive decoder.  Replaces the loop of Faceformer.predict

@@ -1,0 +1,57 @@
+"""Minimal reproduction of the concurrency hazard that shaped SamplingPipeline.run (dev tool).
+
+conv layer 0 (moments -> finalize -> apply, one stream) next to a loop of small GEMM launches on a second stream:
+rows at both ends of conv0's 2 GB output come out wrong although its inputs (audio, GroupNorm scale/shift) are exact;
+the same work run serially, or next to ONE long-running kernel on the second stream, is bit-exact.
+  python scripts/diag_concurrency.py overlap | serial      (PRIO=0 for a normal-priority second stream)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from avi_talking_amd import weights as W, ops, lib as L
+from avi_talking_amd.host.pipeline import SamplingPipeline
+dev = torch.device("cuda:0")
+pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=dev, joint_norm=False)
+B, N = 32, 160000
+g = torch.Generator().manual_seed(4242)
+pcm = (torch.randn(B, N, generator=g) * 3000).clamp(-32768, 32767).to(torch.int16).to(dev)
+am = pipe.talking_head.audio_model
+T0 = (N - 10) // 5 + 1
+MODE = sys.argv[1]
+bn = pipe.prior.voxel2clip
+pw = bn.mlp[0][0]
+xin = torch.ones(32, 4096, device=dev)
+parts = torch.empty((16, 32, 4096), device=dev)
+x = ops.audio_normalize(pcm, joint=False)
+y = torch.empty((B, T0, 512), dtype=torch.float32, device=dev)
+mom = torch.empty((65 * B,), dtype=torch.float64, device=dev)
+ss = torch.empty((1024 * B,), dtype=torch.float32, device=dev)
+side = pipe.side if os.environ.get('PRIO', '-1') == '-1' else torch.cuda.Stream(device=dev, priority=int(os.environ['PRIO']))
+print('side stream priority', side.priority)
+def conv0():
+    L.check(L.load().avi_conv0_gn_gelu(x.data_ptr(), B, N, am.w0.data_ptr(), am.gn_g.data_ptr(), am.gn_b.data_ptr(), 1e-5,
+                                       y.data_ptr(), mom.data_ptr(), ss.data_ptr(), L.stream_ptr()), "conv0")
+def gemms(n):
+    for _ in range(n):
+        ops.gemm_raw(A=xin.data_ptr(), lda=4096, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=parts.data_ptr(), ldc=4096,
+                     M=int(os.environ.get("GM", "32")), N=4096, K=256, prec=3, batch=16, sA=(256, 0), sW=(256, 0), sC=(32 * 4096, 0), ldw=4096)
+conv0(); torch.cuda.synchronize()
+good = y.clone(); ss_good = ss.clone(); mom_good = mom.clone()
+ssr = ss.view(B, 2, 512)
+wins = x[0][: 200 * 5 + 10].unfold(0, 10, 5)[:200]
+full = F.gelu(wins @ am.w0.t() * ssr[0, 0] + ssr[0, 1])
+print("standalone conv0 vs host formula (clip 0, t<200):", (good[0, :200] - full).abs().max().item())
+for it in range(4):
+    y.zero_(); torch.cuda.synchronize()
+    cur = torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        gemms(12)
+    if MODE == "overlap":
+        conv0()
+    torch.cuda.synchronize()
+    if MODE != "overlap":
+        conv0(); torch.cuda.synchronize()
+    print("   ss max diff vs standalone:", (ss - ss_good).abs().max().item(), " mom rel diff:", ((mom - mom_good).abs() / mom_good.abs().clamp_min(1e-30)).max().item())
+    d = (y - good).abs()
+    per = d.view(B, -1).amax(1)
+    print(f"iter {it} [{MODE}] y vs standalone: clips off {(per > 0).nonzero().flatten().tolist()} max {d.max().item():.3e} n {(d > 0).sum().item()}")

@@ -1,0 +1,58 @@
+"""Size-independent properties of the sampling path at BASELINE.json's full config[1] size (32 clips x 10 s,
+100-step DDPM), where the CPU oracle is too slow to be the checker:
+
+* utterances are independent: permuting the batch permutes the outputs BIT-EXACTLY (every output element is reduced
+  in a fixed order that does not depend on which rows share its GEMM tile, attention workgroup or split-K slice);
+* a sub-batch reproduces the rows of the full batch (the oracle pins those rows at small sizes elsewhere);
+* hipGraph replays equal the eager pass, run to run, and BOTH equal a fully serial pass (sampler and audio encoder on
+  one stream): the two-stream overlap must not change a single bit.  (An earlier arrangement, with the aligner's
+  dozen small launches next to conv layer 0, did: scripts/diag_concurrency.py.)
+Per-clip audio normalisation is used so that clips do not interact through the batch statistics (the joint mode of
+AudioEncoders.py:170-178 couples them by design and is covered at small sizes by tests/test_gpu_emote.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    pcm = (torch.randn(B, 160000, generator=g) * 3000).clamp(-32768, 32767).to(torch.int16)
+    voxel = torch.randn(B, 768, generator=g)
+    noise = torch.randn(101, B, 1, 128, generator=g)
+    return pcm, voxel, noise
+
+
+def test_config1_batch_permutation_and_subbatch(gpu):
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu,
+                            joint_norm=False)
+    B = 32
+    pcm, voxel, noise = (t.to(gpu) for t in _inputs(B, 4242))
+    out = pipe.run(pcm, voxel, noise)
+    exp, jaw = out["predicted_exp"].clone(), out["predicted_jaw"].clone()
+    assert exp.shape == (B, 250, 50) and jaw.shape == (B, 250, 3)
+    assert torch.isfinite(exp).all() and torch.isfinite(jaw).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).to(gpu)
+    outp = pipe.run(pcm[perm].contiguous(), voxel[perm].contiguous(), noise[:, perm].contiguous())
+    assert torch.equal(outp["predicted_exp"], exp[perm]) and torch.equal(outp["predicted_jaw"], jaw[perm])
+    # a sub-batch (different tile fill, different number of sampler workgroups) reproduces its rows
+    sub = [3, 17, 30]
+    outs = pipe.run(pcm[sub].contiguous(), voxel[sub].contiguous(), noise[:, sub].contiguous())
+    assert (outs["predicted_exp"] - exp[sub]).abs().max().item() < 1e-5
+    assert (outs["predicted_jaw"] - jaw[sub]).abs().max().item() < 1e-5
+    # fully serial reference: everything on the current stream
+    side, pipe.side = pipe.side, torch.cuda.current_stream(gpu)
+    try:
+        ser = pipe.run(pcm, voxel, noise)
+        torch.cuda.synchronize()
+    finally:
+        pipe.side = side
+    assert torch.equal(ser["predicted_exp"], exp) and torch.equal(ser["predicted_jaw"], jaw)
+    # graph replays == eager == serial, several times
+    pipe.capture(pcm, voxel, noise)
+    for _ in range(4):
+        rep = pipe.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rep["predicted_exp"], exp) and torch.equal(rep["predicted_jaw"], jaw)
