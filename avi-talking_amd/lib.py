@@ -34,6 +34,11 @@ class AviGemm(C.Structure):
     ]
 
 
+class AviFlameBasis(C.Structure):
+    _fields_ = [(n, _vp) for n in ("v_template", "shape_basis", "frame_basis", "j_template", "j_shape", "j_exp",
+                                   "lbs_weights")] + [("V", _i), ("n_shape", _i), ("n_exp", _i)]
+
+
 PRIOR_MAX_DEPTH = 8
 
 
@@ -74,6 +79,7 @@ SIGNATURES = {
     "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "avi_flame_vertices": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "avi_splitk_epilogue": [_vp, _i, _ll, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],

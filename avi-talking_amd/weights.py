@@ -198,3 +198,26 @@ def make_prior_weights(seed=3, dim=128, depth=6, dim_head=64, heads=8, ff_mult=4
     I.norm(c + "norm", dim, bias=False, wname="g")
     I.linear(c + "project_out", dim, dim, bias=False)
     return I.w
+
+
+def make_flame_basis(seed=4, n_vertices=5023, n_shape=300, n_exp=50):
+    """Synthetic FLAME model with the buffer names, shapes and kinematic tree of the licensed ``generic_model.pkl``
+    (absent; DecaFLAME.py:60-85): v_template (V,3), shapedirs (V,3,n_shape+n_exp), posedirs (36, V*3),
+    J_regressor (5,V) (rows sum to 1, sparse support like the real one), lbs_weights (V,5) (rows sum to 1),
+    parents [-1,0,1,1,1] (global, neck, jaw, left eye, right eye).  Magnitudes follow the real model's scale
+    (head ~0.2 m, millimetre blend shapes)."""
+    g = torch.Generator().manual_seed(seed)
+    V = n_vertices
+    r = lambda *s: torch.randn(*s, generator=g)
+    v_template = r(V, 3) * 0.08
+    shapedirs = r(V, 3, n_shape + n_exp) * 1.5e-3
+    posedirs = r(36, V * 3) * 2e-3
+    Jr = torch.zeros(5, V)
+    for j in range(5):
+        idx = torch.randperm(V, generator=g)[:40]
+        w = torch.rand(40, generator=g)
+        Jr[j, idx] = w / w.sum()
+    lw = torch.rand(V, 5, generator=g) ** 4
+    lw = lw / lw.sum(1, keepdim=True)
+    return {"v_template": v_template, "shapedirs": shapedirs, "posedirs": posedirs, "J_regressor": Jr,
+            "lbs_weights": lw, "parents": torch.tensor([-1, 0, 1, 1, 1], dtype=torch.long)}

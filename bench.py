@@ -128,6 +128,12 @@ def main():
             cpu_baseline = measure_cpu_baseline(wa, wh, wp)
     del pipe
     torch.cuda.empty_cache()
+    flame = None
+    if rank == 0 and not args.no_train:
+        try:
+            flame = measure_flame(dev)
+        except Exception as e:
+            flame = {"error": f"{type(e).__name__}: {e}"[:300]}
     train = None
     if not args.no_train:
         try:
@@ -147,11 +153,36 @@ def main():
                        "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
             "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
             "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "train": train,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "train": train, "flame": flame,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_flame(dev, reps=10):
+    """SURVEY 8f row 1 (next after the hot path): FLAME vertices of the config[1] output, 32 x 250 frames x 5023
+    vertices (synthetic basis: the licensed model is absent).  HBM-bound: 482 MB of vertices per pass."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.flame import FLAME
+    fl = FLAME(W.make_flame_basis(4), device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    shape = torch.randn(B_CLIPS, 300, device=dev, generator=g)
+    exp = torch.randn(B_CLIPS, T_FRAMES, 50, device=dev, generator=g) * 0.8
+    jaw = torch.randn(B_CLIPS, T_FRAMES, 3, device=dev, generator=g) * 0.1
+    for _ in range(2):
+        v = fl.from_coefficients(shape, exp, jaw)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        v = fl.from_coefficients(shape, exp, jaw)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = v.numel() * 4
+    return {"workload": "FLAME LBS vertices, 32 clips x 250 frames x 5023 vertices (synthetic basis)",
+            "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(B_CLIPS * T_FRAMES / dt, 1),
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(nbytes / dt / 8e12, 4)}}
 
 
 def measure_train(wp, dev, world, rank, local_rank, dist, args):

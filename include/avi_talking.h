@@ -316,6 +316,28 @@ int avi_adamw(float* p, const float* g, float* m, float* v, long long n, float l
               float weight_decay, int step, float grad_scale, const float* dyn, uint16_t* hi, uint16_t* lo,
               void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FLAME vertices.  Replaces `FLAME.forward(shape_params, expression_params, pose_params,
+ * eye_pose_params)[0]` (third_party/inferno/inferno/models/DecaFLAME.py:222-244) = `lbs` of
+ * third_party/inferno/inferno/utils/lbs.py:142-235 on the 5-joint head model (parents [-1,0,1,1,1]); landmarks are
+ * not produced.  The basis arrays are the FLAME buffers re-laid out once per model:
+ *   shape_basis[k][v*3+c] = shapedirs[v][c][k] (k < n_shape), frame_basis = [expression directions | posedirs rows]
+ *   ((n_exp + 36) x V*3), j_* = J_regressor folded into template / shape / expression bases. */
+typedef struct AviFlameBasis {
+    const float* v_template;   /* [V][3] */
+    const float* shape_basis;  /* [n_shape][V*3] */
+    const float* frame_basis;  /* [n_exp + 36][V*3] */
+    const float* j_template;   /* [5][3]          J_regressor . v_template */
+    const float* j_shape;      /* [5*3][n_shape]  J_regressor . shapedirs[..., :n_shape] */
+    const float* j_exp;        /* [5*3][n_exp] */
+    const float* lbs_weights;  /* [V][5] */
+    int V, n_shape, n_exp;
+} AviFlameBasis;
+/* shape [B][n_shape] (one per clip), exp [B*T][n_exp], pose [B*T][15] = axis-angle of (global, neck, jaw, eye_l, eye_r)
+ * -> verts [B*T][V][3].  Scratch: v_shaped B*V*3 floats, coef ceil(B*T/8)*8*(n_exp+36) floats, xf B*T*60 floats. */
+int avi_flame_vertices(const AviFlameBasis* fb, const float* shape, const float* exp, const float* pose, int B, int T,
+                       float* v_shaped, float* coef, float* xf, float* verts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,9 @@ What is pinned:
                      ``__new__`` + hand-attached submodules (``__init__`` needs FLAME assets, the network and
                      files that do not exist in the repo); the FAN image encoder (out of scope) is a stub
                      returning zero embeddings.
+  * flame.npz        inferno ``utils/lbs.py`` ``lbs`` (imported as is: pure torch) on the synthetic FLAME basis of
+                     avi_talking_amd.weights.make_flame_basis, with the pose assembly of ``FLAME.forward``
+                     (DecaFLAME.py:236-244); inputs + a slice of the vertices.
 Absent packages (cv2, easydict, omegaconf, torchvision, clip, dalle2_pytorch, gdl, pirender ...) are
 replaced by MagicMock modules so the reference files import; none of the mocked symbols is on the
 executed path.  The dalle2-based prior classes cannot be executed (dalle2_pytorch absent): unpinned.
@@ -192,8 +195,35 @@ def gen_faceformer(ff):
         print("faceformer", D, tuple(out.shape))
 
 
+def gen_flame():
+    lbs_mod = load_by_path("ref_lbs", os.path.join(REF, "third_party/inferno/inferno/utils/lbs.py"))
+    basis = W.make_flame_basis(4)
+    g = torch.Generator().manual_seed(21)
+    N = 6
+    shape = torch.randn(N, 300, generator=g)
+    exp = torch.randn(N, 50, generator=g) * 0.8
+    pose = torch.randn(N, 6, generator=g) * torch.tensor([0.1, 0.1, 0.1, 0.25, 0.05, 0.05])
+    pose[0] = 0.0                                                    # rest pose: exercises the 1e-8 epsilon path
+    eye = torch.randn(N, 6, generator=g) * 0.1
+    neck = torch.randn(N, 3, generator=g) * 0.1
+    betas = torch.cat([shape, exp], 1)
+    full_pose = torch.cat([pose[:, :3], neck, pose[:, 3:], eye], 1)  # DecaFLAME.py:240-241
+    with torch.no_grad():
+        v, J = lbs_mod.lbs(betas, full_pose, basis["v_template"][None].expand(N, -1, -1), basis["shapedirs"],
+                           basis["posedirs"], basis["J_regressor"], basis["parents"], basis["lbs_weights"])
+    idx = torch.arange(0, 5023, 17)
+    np.savez_compressed(os.path.join(HERE, "flame.npz"), shape=shape.numpy(), exp=exp.numpy(), pose=pose.numpy(),
+                        eye=eye.numpy(), neck=neck.numpy(), vidx=idx.numpy(), verts=v[:, idx].numpy(),
+                        joints=J.numpy(), vsum=v.double().sum((1, 2)).numpy())
+    print("flame.npz: verts", tuple(v.shape), "slice", tuple(v[:, idx].shape))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "flame":      # regenerate only the FLAME fixture
+        gen_flame()
+        sys.exit(0)
+    gen_flame()
     gen_wav2vec2()
     ff, dp = import_reference_models()
     gen_masks(ff)

@@ -81,3 +81,17 @@ def test_coeff_stats_fixture():
     m, s = _load("coeff_mean.npy"), _load("coeff_std.npy")
     assert m.shape == (53,) and s.shape == (53,) and m.dtype == np.float32
     assert np.allclose(s[50:53], [0.04804965, 0.0071304, 0.02132538])
+
+
+def test_flame_lbs_matches_reference_lbs():
+    """oracle/flame.py against the reference's own lbs() (tests/golden/flame.npz, synthetic basis)."""
+    from avi_talking_amd.weights import make_flame_basis
+    from oracle import flame as OF
+    g = np.load(os.path.join(G, "flame.npz"))
+    basis = make_flame_basis(4)
+    t = lambda k: torch.from_numpy(g[k])
+    v = OF.flame_forward(basis, t("shape"), t("exp"), t("pose"), eye_pose_params=t("eye"), neck_pose=t("neck"))
+    assert v.shape == (6, 5023, 3)
+    err = (v[:, torch.from_numpy(g["vidx"])] - t("verts")).abs().max().item()
+    assert err < 1e-6, err
+    assert np.abs(v.double().sum((1, 2)).numpy() - g["vsum"]).max() < 1e-4
