@@ -55,3 +55,20 @@ for it in range(4):
     d = (y - good).abs()
     per = d.view(B, -1).amax(1)
     print(f"iter {it} [{MODE}] y vs standalone: clips off {(per > 0).nonzero().flatten().tolist()} max {d.max().item():.3e} n {(d > 0).sum().item()}")
+if MODE == "overlap":
+    dd = d.view(B, T0, 512)
+    bad_all = (dd > 1e-6).nonzero()
+    print("wrong elements:", bad_all.shape[0], bad_all[:6].tolist())
+    if bad_all.numel():
+        bb, t0_, _ = bad_all[0].tolist()
+        lo = max(0, t0_ - 200); Tn = min(T0 - lo, 400)
+        wins = x[bb][lo * 5: (lo + Tn) * 5 + 10].unfold(0, 10, 5)[:Tn]
+        pre = wins @ am.w0.t()
+        full = F.gelu(pre * ssr[bb, 0] + ssr[bb, 1])
+        sel = [e for e in bad_all.tolist() if e[0] == bb and lo <= e[1] < lo + Tn][:10]
+        for (_, t, c) in sel:
+            v = y[bb, t, c].item(); tl = t - lo
+            hit = ((full - v).abs() < 1e-5).nonzero().tolist()
+            alt = [cc for cc in range(512) if abs(F.gelu(pre[tl, c] * ssr[bb, 0, cc] + ssr[bb, 1, cc]).item() - v) < 1e-5]
+            altb = [b2 for b2 in range(B) if abs(F.gelu(pre[tl, c] * ssr[b2, 0, c] + ssr[b2, 1, c]).item() - v) < 1e-5]
+            print(f"  y[{bb}][{t}][{c}] = {v:.6f}, correct {full[tl, c].item():.6f}; in table at {[(a + lo, b_) for a, b_ in hit[:4]]}; own conv with channel-ss {alt[:4]}; own conv with clip-ss {altb[:6]}; zero {abs(v) < 1e-12}")
