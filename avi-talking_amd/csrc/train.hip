@@ -185,23 +185,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 }
 
 // dgamma[c] (+)= sum_r dy*mask*act'(u)*xhat ;  dbeta[c] (+)= sum_r dy*mask*act'(u)
-__global__ void ln_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     const float* __restrict__ mask, const float* __restrict__ stats, int rows, int C,
-                                     int act, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float g = gamma[c], b = beta ? beta[c] : 0.f;
+// block = 64 columns x 4 row groups (a serial walk over the rows by one thread per column cost 50 us per call, 18 % of
+// the training step); partial sums meet in LDS in a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mask,
+                                                             const float* __restrict__ stats, int rows, int C, int act,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate) {
+    __shared__ float pg[4][64], pb[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float sg = 0.f, sb = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const float mean = stats[r * 3], rstd = stats[r * 3 + 1], pre = stats[r * 3 + 2];
-        const float xh = (x[(long long)r * C + c] * pre - mean) * rstd;
-        const float t = dy[(long long)r * C + c] * (mask ? mask[(long long)r * C + c] : 1.f) * act_grad(xh * g + b, act);
-        sg += t * xh;
-        sb += t;
+    if (c < C) {
+        const float g = gamma[c], b = beta ? beta[c] : 0.f;
+#pragma unroll 4
+        for (int r = ty; r < rows; r += 4) {
+            const float mean = stats[r * 3], rstd = stats[r * 3 + 1], pre = stats[r * 3 + 2];
+            const float xh = (x[(long long)r * C + c] * pre - mean) * rstd;
+            const float t =
+                dy[(long long)r * C + c] * (mask ? mask[(long long)r * C + c] : 1.f) * act_grad(xh * g + b, act);
+            sg += t * xh;
+            sb += t;
+        }
     }
-    dgamma[c] = accumulate ? dgamma[c] + sg : sg;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+    pg[ty][tx] = sg;
+    pb[ty][tx] = sb;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]);
+        sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
+        dgamma[c] = accumulate ? dgamma[c] + sg : sg;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+    }
 }
 
 // ------------------------------------------------------------------ prior: token assembly + q_sample
@@ -622,7 +639,7 @@ extern "C" int avi_layernorm_bwd(const float* x, const float* dy, const float* g
     else
         hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, s, x, dy, gamma, beta, mask, rows, C, eps, act, stable,
                            dx_add, dx, stats);
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, dy, gamma, beta, mask, stats,
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, dy, gamma, beta, mask, stats,
                        rows, C, act, dgamma, dbeta, accumulate);
     return avi_launch_status();
 }

@@ -65,8 +65,26 @@ class _Lin:
         L.check(so.avi_pack_weight_split(self._tmp.data_ptr(), self.K, self.N, self.K, self.hiT.data_ptr(),
                                          self.loT.data_ptr(), L.stream_ptr()), "pack")
 
+    @staticmethod
+    def _skinny(A, lda, Whi, Wlo, M, N, K, bias=0, act=ops.ACT_NONE, residual=None, kslice=256):
+        """y = act(A W^T + bias) + residual for a few rows and a long K (the aligner at batch-size rows): K slices as
+        one batched launch (hundreds of workgroups stream the weights) + avi_splitk_epilogue, instead of a 128-row tile
+        GEMM on N/128 workgroups (125 us per 4096x4096 layer)."""
+        nz = K // kslice
+        dev = A.device
+        parts = torch.empty((nz, M, N), dtype=torch.float32, device=dev)
+        ops.gemm_raw(A=A.data_ptr(), lda=lda, Whi=Whi, Wlo=Wlo, C_=parts.data_ptr(), ldc=N, M=M, N=N, K=kslice,
+                     batch=nz, sA=(kslice, 0), sW=(kslice, 0), sC=(M * N, 0), ldw=K)
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        L.check(L.load().avi_splitk_epilogue(parts.data_ptr(), nz, M * N, M, N, bias or None, None, None, 1e-5, 0, act,
+                                             L.ptr(residual), y.data_ptr(), L.stream_ptr()), "avi_splitk_epilogue")
+        return y
+
     def fwd(self, x, act=ops.ACT_NONE):
         M = x.numel() // self.K
+        if M <= 128 and self.K >= 1024 and self.K % 256 == 0 and self.N % 4 == 0 and self.N <= 4096:
+            return self._skinny(x, self.K, self.s.hi_ptr(self.w), self.s.lo_ptr(self.w), M, self.N, self.K,
+                                bias=self.s.ptr(self.b) if self.b else 0, act=act)
         y = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
         ops.gemm_raw(A=x.data_ptr(), lda=self.K, Whi=self.s.hi_ptr(self.w), Wlo=self.s.lo_ptr(self.w), C_=y.data_ptr(),
                      ldc=self.N, M=M, N=self.N, K=self.K, bias=self.s.ptr(self.b) if self.b else 0, act=act)
@@ -90,6 +108,9 @@ class _Lin:
             L.check(so.avi_colsum(dy.data_ptr(), M, self.N, self.s.gptr(self.b), 0, L.stream_ptr()), "colsum")
         if not self.need_dx:
             return None
+        if M <= 128 and self.N >= 1024 and self.N % 256 == 0 and self.K % 4 == 0 and self.K <= 4096:
+            return self._skinny(dy, self.N, self.hiT.data_ptr(), self.loT.data_ptr(), M, self.K, self.N,
+                                residual=dx_residual)
         dx = torch.empty((M, self.K), dtype=torch.float32, device=dev)
         ops.gemm_raw(A=dy.data_ptr(), lda=self.N, Whi=self.hiT.data_ptr(), Wlo=self.loT.data_ptr(), C_=dx.data_ptr(),
                      ldc=self.K, M=M, N=self.K, K=self.N, R=L.ptr(dx_residual), ldr=self.K)
