@@ -29,6 +29,29 @@ __global__ void transpose_kernel(const float* __restrict__ in, int R, int Cc, fl
     }
 }
 
+// out_hi/out_lo [C_pad][R] = bf16 split of in^T (rows >= Cc zero): the transposed operand of a GEMM in one pass
+// (the training step used to run a transpose and then a pack kernel for every layer, every step).
+__global__ void transpose_pack_kernel(const float* __restrict__ in, int R, int Cc, int C_pad,
+                                      uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < R && c < Cc) ? in[(long long)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (c < C_pad && r < R) {
+            const float x = tile[tx][j];
+            const __bf16 h = (__bf16)x;
+            hi[(long long)c * R + r] = __builtin_bit_cast(uint16_t, h);
+            lo[(long long)c * R + r] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+        }
+    }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ in, int R, int Cc, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cc) return;
@@ -596,6 +619,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 extern "C" int avi_transpose(const float* in, int R, int Cc, float* out, void* stream) {
     if (!in || !out || R <= 0 || Cc <= 0) return AVI_EINVAL;
     hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, S_(stream), in, R, Cc, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pad, uint16_t* hi, uint16_t* lo,
+                                        void* stream) {
+    if (!in || !hi || !lo || R <= 0 || Cc <= 0 || C_pad < Cc) return AVI_EINVAL;
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3((C_pad + 31) / 32, (R + 31) / 32), dim3(256), 0, S_(stream), in, R,
+                       Cc, C_pad, hi, lo);
     return avi_launch_status();
 }
 

@@ -53,17 +53,15 @@ class _Lin:
         self.need_dx = need_dx
         if need_dx:
             dev = store.P.device
-            self.hiT = torch.empty((self.K, self.N), dtype=torch.int16, device=dev)
+            self.Kp = 64 if self.K <= 64 else (self.K + 127) // 128 * 128        # row padding of a GEMM weight operand
+            self.hiT = torch.empty((self.Kp, self.N), dtype=torch.int16, device=dev)
             self.loT = torch.empty_like(self.hiT)
-            self._tmp = torch.empty((self.K, self.N), dtype=torch.float32, device=dev)
 
     def refresh_transposed(self):
         if not self.need_dx:
             return
-        so = L.load()
-        L.check(so.avi_transpose(self.s.ptr(self.w), self.N, self.K, self._tmp.data_ptr(), L.stream_ptr()), "transpose")
-        L.check(so.avi_pack_weight_split(self._tmp.data_ptr(), self.K, self.N, self.K, self.hiT.data_ptr(),
-                                         self.loT.data_ptr(), L.stream_ptr()), "pack")
+        L.check(L.load().avi_transpose_pack_split(self.s.ptr(self.w), self.N, self.K, self.Kp, self.hiT.data_ptr(),
+                                                  self.loT.data_ptr(), L.stream_ptr()), "avi_transpose_pack_split")
 
     @staticmethod
     def _skinny(A, lda, Whi, Wlo, M, N, K, bias=0, act=ops.ACT_NONE, residual=None, kslice=256):
@@ -98,11 +96,13 @@ class _Lin:
             raise ValueError("training batch rows must be a multiple of 64")
         dev = dy.device
         dyT = torch.empty((self.N, M), dtype=torch.float32, device=dev)
-        xT = torch.empty((self.K, M), dtype=torch.float32, device=dev)
         L.check(so.avi_transpose(dy.data_ptr(), M, self.N, dyT.data_ptr(), L.stream_ptr()), "transpose")
-        L.check(so.avi_transpose(x.data_ptr(), M, self.K, xT.data_ptr(), L.stream_ptr()), "transpose")
-        xT_pack = ops.PackedWeight(xT)                       # [K][M] hi/lo: the "weight" operand of the dW GEMM
-        ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xT_pack.hi.data_ptr(), Wlo=xT_pack.lo.data_ptr(),
+        Kp = 64 if self.K <= 64 else (self.K + 127) // 128 * 128
+        xhi = torch.empty((Kp, M), dtype=torch.int16, device=dev)      # x^T as [K][M] hi/lo: the "weight" operand of
+        xlo = torch.empty_like(xhi)                                    # the dW GEMM, transposed and split in one pass
+        L.check(so.avi_transpose_pack_split(x.data_ptr(), M, self.K, Kp, xhi.data_ptr(), xlo.data_ptr(), L.stream_ptr()),
+                "avi_transpose_pack_split")
+        ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xhi.data_ptr(), Wlo=xlo.data_ptr(),
                      C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
         if self.b:
             L.check(so.avi_colsum(dy.data_ptr(), M, self.N, self.s.gptr(self.b), 0, L.stream_ptr()), "colsum")

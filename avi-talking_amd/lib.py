@@ -80,6 +80,7 @@ SIGNATURES = {
     "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "avi_flame_vertices": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "avi_transpose_pack_split": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "avi_splitk_epilogue": [_vp, _i, _ll, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],

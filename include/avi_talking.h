@@ -276,7 +276,10 @@ int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const
 int avi_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mask,
                       int rows, int C, float eps, int act, int stable, const float* dx_add, float* dx, float* dgamma,
                       float* dbeta, int accumulate, float* stats, void* stream);   /* dx = dLN/dx + dx_add (or NULL) */
-int avi_transpose(const float* in, int R, int C, float* out, void* stream);                 /* [R][C] -> [C][R] */
+int avi_transpose(const float* in, int R, int C, float* out, void* stream);                 /* hi/lo [C_pad][R] = bf16 hi/lo split of in^T (in is [R][Cc] fp32; rows Cc..C_pad-1 are zero): the transposed
+ * "weight" operand of avi_gemm for dW = dY^T X and dX = dY W in one pass. */
+int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pad, uint16_t* hi, uint16_t* lo, void* stream);
+/* [R][C] -> [C][R] */
 int avi_colsum(const float* in, int R, int C, float* out, int accumulate, void* stream);     /* out[c] = sum_r */
 int avi_act_fwd(const float* x, long long n, int act, float* y, void* stream);
 int avi_act_bwd(const float* x_pre, const float* dy, long long n, int act, float* dx, void* stream);
