@@ -434,14 +434,15 @@ bool avi_gemm_pp_ok(const AviGemm& g);
 int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s);
 // gemm_pp192.hip: the same schedule on 128x192 tiles (transformer projections: M = 8000, N = 768 / 2304 / 3072)
 bool avi_gemm_pp192_ok(const AviGemm& g);
-int avi_gemm_pp192_launch(const AviGemm& g, hipStream_t s);
+int avi_gemm_pp192_launch(const AviGemm& g, int bn, hipStream_t s);
 
 // Fraction of the launched tile area that is useful work when `cus` workgroups run per round (1 per CU), times a
 // per-tile efficiency (the smaller tile moves more LDS-DMA pieces per MFMA): picks the tile shape for a problem.
 static double tile_score(const AviGemm& g, int bm, int bn, double eff) {
+    const int cus = g.cus > 0 && g.cus <= 256 ? g.cus : 256;
     const long long tiles = (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch;
-    const long long rounds = (tiles + 255) / 256;
-    return eff * (double)g.M * g.N * g.batch / ((double)rounds * 256 * bm * bn);
+    const long long rounds = (tiles + cus - 1) / cus;
+    return eff * (double)g.M * g.N * g.batch / ((double)rounds * cus * bm * bn);
 }
 
 static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3: double-buffered v2 kernel for fp32 A; 2/4/5: see below
@@ -481,13 +482,17 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (planes) {   // AVI_GEMM_KERNEL=2 keeps the one-phase LDS-DMA kernel, 4 / 5 force one ping-pong tile shape
         const int choice = gemm_kernel_choice();
-        const bool ok256 = avi_gemm_pp_ok(g) && choice != 2 && choice != 5;
-        const bool ok192 = avi_gemm_pp192_ok(g) && choice != 2 && choice != 4;
-        if (ok256 && ok192)
-            return tile_score(g, 128, 192, 0.85) > tile_score(g, 256, 256, 1.0) ? avi_gemm_pp192_launch(g, s)
-                                                                                   : avi_gemm_pp_launch(g, s);
-        if (ok256) return avi_gemm_pp_launch(g, s);
-        if (ok192) return avi_gemm_pp192_launch(g, s);
+        const bool ok256 = avi_gemm_pp_ok(g) && choice != 2 && choice != 5 && choice != 6;
+        const bool ok128 = avi_gemm_pp192_ok(g) && choice != 2 && choice != 4;
+        // candidates: 256x256 (eff 1.0), 128x256 (0.88), 128x192 (0.85); 5 / 6 force 128x192 / 128x256
+        double best = -1.0;
+        int pick = 0;
+        if (ok256) { best = tile_score(g, 256, 256, 1.0); pick = 1; }
+        if (ok128 && choice != 6) { const double v = tile_score(g, 128, 192, 0.85); if (v > best) { best = v; pick = 2; } }
+        if (ok128 && choice != 5) { const double v = tile_score(g, 128, 256, 0.88); if (v > best) { best = v; pick = 3; } }
+        if (pick == 1) return avi_gemm_pp_launch(g, s);
+        if (pick == 2) return avi_gemm_pp192_launch(g, 192, s);
+        if (pick == 3) return avi_gemm_pp192_launch(g, 256, s);
         return avi_gemm_dma_launch(g, s);
     }
     const bool narrow = g.N <= 64;

@@ -22,13 +22,24 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 192, NTHR = 512;
-constexpr int X_BYTES = 64 * 128, W_BYTES = 192 * 128;
-constexpr int STAGE_BYTES = 2 * X_BYTES + W_BYTES;    // 40 KiB
+// NT = n-tiles per wave: 3 -> 128 x 192 tile, 4 -> 128 x 256 tile (189 tiles at M = 8000, N = 768: ONE round when the
+// sampler holds 32 of the 256 CUs, where 252 tiles of 128 x 192 need two)
+constexpr int BM = 128, NTHR = 512;
+constexpr int X_BYTES = 64 * 128;
 constexpr int NSTAGE = 3;
-constexpr int EP_STRIDE = 208;                        // epilogue slab: 48 fp32 + 16 B pad per row
-constexpr int EP_SLAB = 64 * EP_STRIDE;
-constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;      // 120 KiB (>= 8 epilogue slabs = 104 KiB)
+template <int NT> struct Geo {
+    static constexpr int BN = 64 * NT, W_BYTES = BN * 128;
+    static constexpr int STAGE_BYTES = 2 * X_BYTES + W_BYTES;          // 40 / 48 KiB
+    static constexpr int EP_STRIDE = 64 * NT + 16;                     // epilogue slab row: 16 NT fp32 + 16 B pad
+    static constexpr int EP_SLAB = 64 * EP_STRIDE;
+    static constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;            // 120 / 144 KiB (>= 8 slabs = 104 / 136 KiB)
+};
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 4 && N <= 6, "vmcnt literal");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -37,8 +48,10 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NS>
+template <int NS, int NT>
 __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+    constexpr int BN = Geo<NT>::BN, STAGE_BYTES = Geo<NT>::STAGE_BYTES, EP_STRIDE = Geo<NT>::EP_STRIDE,
+                  EP_SLAB = Geo<NT>::EP_SLAB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     constexpr int KB = NS == 2 ? 64 : 128;   // bytes one K tile advances along a row of a plane
     const long long ldw = g.ldw ? g.ldw : g.K;
     const char* xsrc[2];
-    const char* wsrc[3];
+    const char* wsrc[NT];
     {
         const int R = wave * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (R & 7);
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
         }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NT; ++i) {
         const int R = (wave + 8 * i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (R & 7);
         const int off = NS == 2 ? (c & 3) * 16 : c * 16;
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
         const long long kofs = (long long)(T < nk ? T : nk - 1) * KB;
         char* dst = smem + stage * STAGE_BYTES + 2 * X_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) glds16(wsrc[i] + kofs, dst + i * 8 * 1024);
+        for (int i = 0; i < NT; ++i) glds16(wsrc[i] + kofs, dst + i * 8 * 1024);
     };
     auto issue_x = [&](int T, int stage) __attribute__((always_inline)) {
         const long long kofs = (long long)(T < nk ? T : nk - 1) * KB;
@@ -108,13 +121,13 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     const int fr = lane & 15, fq = lane >> 4;
     const int pos = (fq ^ (fr & 7)) << 4;
     const int xoff = (wr * 32 + fr) * 128 + pos;                   // + stage, + h * X_BYTES, + bl * 2048
-    const int woff = 2 * X_BYTES + (wc * 48 + fr) * 128 + pos;     // + stage, + a * 2048
+    const int woff = 2 * X_BYTES + (wc * (16 * NT) + fr) * 128 + pos;   // + stage, + a * 2048
     const char* xhi_p = smem + xoff;
     const char* xlo_p = smem + (xoff ^ 64);
     const char* whi_p = smem + woff;
     const char* wlo_p = smem + (woff ^ 64);
 
-    bf16x8 xh[2], xl[2], wh[3], wl[3];
+    bf16x8 xh[2], xl[2], wh[NT], wl[NT];
     auto read_x = [&](int stage, int h) __attribute__((always_inline)) {
         const int o = stage * STAGE_BYTES + h * X_BYTES;
 #pragma unroll
@@ -126,22 +139,22 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     auto read_w = [&](int stage) __attribute__((always_inline)) {
         const int o = stage * STAGE_BYTES;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < NT; ++a) {
             wh[a] = *reinterpret_cast<const bf16x8*>(whi_p + o + a * 2048);
             wl[a] = *reinterpret_cast<const bf16x8*>(wlo_p + o + a * 2048);
         }
     };
 
-    f32x4 acc[3][4];   // [n tile][m tile]
+    f32x4 acc[NT][4];   // [n tile][m tile]
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto multiply = [&](int mh) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int bl = 0; bl < 2; ++bl) {
                 f32x4 c = acc[a][mh * 2 + bl];
@@ -169,19 +182,19 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     issue_x(0, 0);
     issue_w(1, 1);
     issue_x(1, 1);
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // W(0), X0(0), X1(0) have landed
+    wait_vmcnt<NT + 2>();                                // W(0), X0(0), X1(0) have landed
     bar();
     // ONE barrier per phase: group A (wr = 0) runs memory -> matrix inside a barrier interval, group B matrix (on the
     // fragments it read in the previous interval) -> memory, so the two waves of a SIMD alternate (gemm_pp.hip).
     auto mem_even = [&](int Tu, int u) __attribute__((always_inline)) {   // K tile Tu in stage u
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        wait_vmcnt<NT + 2>();
         issue_w(Tu + 2, u == 0 ? 2 : u - 1);
         read_w(u);
         __builtin_amdgcn_sched_barrier(0);
         read_x(u, 0);
     };
     auto mem_odd = [&](int Tu, int u) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        wait_vmcnt<NT + 1>();
         issue_x(Tu + 2, u == 0 ? 2 : u - 1);
         read_x(u, 1);
     };
@@ -225,17 +238,17 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                         (!Chi || (((reinterpret_cast<uintptr_t>(Chi) | reinterpret_cast<uintptr_t>(Clo)) & 7) == 0));
     char* slab = smem + wave * EP_SLAB;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             *reinterpret_cast<f32x4*>(slab + (b * 16 + fr) * EP_STRIDE + (a * 16 + fq * 4) * 4) = acc[a][b];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, other lanes' rows
-    // 64 rows x 12 float4: item i = lane + 64 it -> row i / 12, columns 4 (i % 12) .. +3
+    // 64 rows x 4 NT float4: item i = lane + 64 it -> row i / (4 NT), columns 4 (i % (4 NT)) .. +3
 #pragma unroll
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < 4 * NT; ++it) {
         const int i = lane + 64 * it;
-        const int row = i / 12, c4 = i - row * 12;
-        const int m = m0 + wr * 64 + row, n = n0 + wc * 48 + c4 * 4;
+        const int row = i / (4 * NT), c4 = i - row * (4 * NT);
+        const int m = m0 + wr * 64 + row, n = n0 + wc * (16 * NT) + c4 * 4;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(slab + row * EP_STRIDE + c4 * 16);
         if (m >= g.M || n >= g.N) continue;
         float v[4];
@@ -288,28 +301,32 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     }
 }
 
-template <int NS>
+template <int NS, int NT>
 int launch(const AviGemm& g, hipStream_t s) {
+    constexpr int BN = Geo<NT>::BN, SMEM_BYTES = Geo<NT>::SMEM_BYTES;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp192_kernel<NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pp192_kernel<NS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+    hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();
 }
 
 }  // namespace
 
-// true when the 128 x 192 kernel can take the problem (K tiles come in threes)
+// true when the 128-row ping-pong kernels can take the problem (K tiles come in threes)
 bool avi_gemm_pp192_ok(const AviGemm& g) {
     const int kt = (g.prec & 0xff) == AVI_PREC_BF16X3 ? 32 : 64;
     return g.Ahi && g.K % (3 * kt) == 0;
 }
 
-int avi_gemm_pp192_launch(const AviGemm& g, hipStream_t s) {
-    return (g.prec & 0xff) == AVI_PREC_BF16X3 ? launch<2>(g, s) : launch<1>(g, s);
+// bn = 192 or 256
+int avi_gemm_pp192_launch(const AviGemm& g, int bn, hipStream_t s) {
+    const bool x3 = (g.prec & 0xff) == AVI_PREC_BF16X3;
+    if (bn == 256) return x3 ? launch<2, 4>(g, s) : launch<1, 4>(g, s);
+    return x3 ? launch<2, 3>(g, s) : launch<1, 3>(g, s);
 }

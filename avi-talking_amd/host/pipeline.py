@@ -56,7 +56,14 @@ class SamplingPipeline:
             style = self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
                                              cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
                                              noise=noise)
-        sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
+        # the sampler's workgroups (one per samples_per_group samples) hold a CU each until the join: GEMM tile shapes of the
+        # audio branch are chosen for the CUs that remain (avi_talking.h AviGemm.cus)
+        spg = max(1, min(self.prior.samples_per_group, B))
+        ops.CU_BUDGET = 256 - (B + spg - 1) // spg if self.prior.samples_per_group > 0 else 256 - B
+        try:
+            sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
+        finally:
+            ops.CU_BUDGET = 0
         # 3. join
         cur.wait_stream(self.side)
         out = self.talking_head.head(sample["audio_feature"], style)

@@ -30,7 +30,7 @@ class AviGemm(C.Structure):
         ("batch", _i), ("z_inner", _i),
         ("act", _i), ("prec", _i),
         ("Ahi", _vp), ("Alo", _vp), ("Chi", _vp), ("Clo", _vp),
-        ("ldw", _i),
+        ("ldw", _i), ("cus", _i),
     ]
 
 

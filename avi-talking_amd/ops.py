@@ -18,6 +18,11 @@ def _f32c(t, name):
     return t
 
 
+# Compute units a GEMM launch can count on (0 = all): the sampling pipeline lowers it while the sampler's workgroups
+# hold CUs on the side stream, so that tile shapes fill whole rounds of the CUs that are actually free.
+CU_BUDGET = 0
+
+
 class PackedWeight:
     """A Linear/Conv weight [N][K] pre-split into bf16 hi/lo parts, rows padded for the GEMM tiles."""
 
@@ -44,6 +49,7 @@ def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0
     """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets)."""
     g = L.AviGemm()
     g.ldw = ldw
+    g.cus = CU_BUDGET
     g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
     g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]

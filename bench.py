@@ -235,17 +235,28 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
 def gemm_family(kw):
     """Which kernel avi_gemm dispatches a launch to (mirrors csrc/gemm.hip avi_gemm)."""
     if kw.get("Ahi"):
+        from avi_talking_amd import ops
         kt = 32 if (kw.get("prec", 3) & 0xff) == 3 else 64
         M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
+        cus = ops.CU_BUDGET if 0 < ops.CU_BUDGET <= 256 else 256
 
         def score(bm, bn, eff):                      # csrc/gemm.hip tile_score
             tiles = -(-M // bm) * -(-N // bn) * batch
-            return eff * M * N * batch / (-(-tiles // 256) * 256 * bm * bn)
+            return eff * M * N * batch / (-(-tiles // cus) * cus * bm * bn)
 
-        ok256, ok192 = K % (2 * kt) == 0, K % (3 * kt) == 0
-        if ok256 and ok192:
-            return "gemm_pp192_kernel" if score(128, 192, 0.85) > score(256, 256, 1.0) else "gemm_pp_kernel"
-        return "gemm_pp_kernel" if ok256 else "gemm_pp192_kernel" if ok192 else "gemm_dma_kernel"
+        cands = []
+        if K % (2 * kt) == 0:
+            cands.append((score(256, 256, 1.0), "gemm_pp_kernel (256x256)"))
+        if K % (3 * kt) == 0:
+            cands.append((score(128, 192, 0.85), "gemm_pp192_kernel<NT=3> (128x192)"))
+            cands.append((score(128, 256, 0.88), "gemm_pp192_kernel<NT=4> (128x256)"))
+        if not cands:
+            return "gemm_dma_kernel"
+        best = cands[0]
+        for c in cands[1:]:
+            if c[0] > best[0]:
+                best = c
+        return best[1]
     return "gemm_kernel<128>" if kw["N"] > 64 else "gemm_kernel<64>"
 
 
@@ -291,8 +302,10 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
     def describe(name):
         ms, fl, n = fam[name]
         ach = fl / (ms * 1e-3) / 1e12
-        t = next((v for k, v in traffic.items() if k.startswith(name.split("<")[0]) and
-                  (name.split("<")[1].rstrip(">") in k if "<" in name else True)), None)
+        base = name.split(" ")[0].split("<")[0]
+        tag = name.split("<")[1].split(">")[0] if "<" in name else ""
+        tag = {"NT=3": ", 3>", "NT=4": ", 4>"}.get(tag, tag)
+        t = next((v for k, v in traffic.items() if k.startswith(base) and (tag in k if tag else True)), None)
         return {"bound": "mfma", "kernel": f"{name} (bf16 MFMA 16x16x32, {ns} MFMA per product)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),

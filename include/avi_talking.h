@@ -76,6 +76,10 @@ typedef struct AviGemm {
      * one weight matrix (split-K for skinny problems: sAo = sWo = K_slice, partial sums per batch entry, folded by
      * avi_splitk_epilogue). */
     int ldw;
+    /* Compute units this launch can count on (0 = all 256).  A caller that knows another kernel holds some CUs for the
+     * whole duration (the sampling pipeline: 32 sampler workgroups) passes the remainder, and the tile shape is chosen
+     * to fill whole rounds of THAT many workgroups. */
+    int cus;
 } AviGemm;
 int avi_gemm(const AviGemm* g, void* stream);
 

@@ -231,3 +231,27 @@ def test_linear_ln_skinny(gpu, M, N, K, do_ln, res):
                                residual=r.to(gpu) if res else None)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 5e-5, err
+
+
+@pytest.mark.parametrize("M,N,K,budget", [(8000, 768, 768, 0), (8000, 768, 768, 224), (8000, 768, 3072, 224),
+                                          (4000, 512, 1536, 224), (333, 256, 192, 224)])
+def test_planes_gemm_tile_shapes(gpu, M, N, K, budget):
+    """The plane-input GEMM picks its tile (256x256 / 128x192 / 128x256) from the fill of the CUs it may count on
+    (ops.CU_BUDGET -> AviGemm.cus); every choice must give the same result."""
+    from avi_talking_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    xp = ops.Planes((M, K), gpu)
+    hi = x.to(torch.bfloat16)
+    xp.hi.copy_(hi.view(torch.int16).to(gpu))
+    xp.lo.copy_((x - hi.float()).to(torch.bfloat16).view(torch.int16).to(gpu))
+    ops.CU_BUDGET = budget
+    try:
+        out = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu)).cpu().double()
+        outp = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu), out_planes=True)
+    finally:
+        ops.CU_BUDGET = 0
+    err = (out - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), err
+    assert (outp.float().cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, (K / 64) ** 0.5) + 1e-4
