@@ -52,6 +52,27 @@ __device__ __forceinline__ float avi_act(float x, int act) {
     }
 }
 
+// Wave-wide sum / max over DPP lanes (quad xor 1, xor 2, half-row mirror, row mirror, row broadcasts), result taken
+// from lane 63 with v_readlane: ~7 vector instructions instead of six ds_bpermute round trips (~100 cycles each).
+// The result is wave-uniform (an SGPR), which the small latency-bound phases of the sampler rely on.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_dpp(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    const float id = MAX ? -3.0e38f : 0.f;
+#define AVI_DPP(x, ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, id), \
+                                     __builtin_bit_cast(int, x), ctrl, rm, 0xF, false))
+    v = op(v, AVI_DPP(v, 0xB1, 0xF));    // quad_perm [1,0,3,2]
+    v = op(v, AVI_DPP(v, 0x4E, 0xF));    // quad_perm [2,3,0,1]
+    v = op(v, AVI_DPP(v, 0x141, 0xF));   // row_half_mirror
+    v = op(v, AVI_DPP(v, 0x140, 0xF));   // row_mirror: every lane of a 16-lane row holds the row's result
+    v = op(v, AVI_DPP(v, 0x142, 0xA));   // row_bcast15 into rows 1 and 3
+    v = op(v, AVI_DPP(v, 0x143, 0xC));   // row_bcast31 into rows 2 and 3: row 3 holds the wave's result
+#undef AVI_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_u(float v) { return wave_reduce_dpp<false>(v); }
+__device__ __forceinline__ float wave_max_u(float v) { return wave_reduce_dpp<true>(v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
