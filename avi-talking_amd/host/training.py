@@ -228,7 +228,7 @@ class PriorTrainer:
         self.c = c
         self.lins = ([self.lin0, self.lin1] + self.mlp + self.proj + self.tm + [self.cproj] +
                      [ly[k] for ly in self.layers for k in ("qkv", "out", "w1", "w2")])
-        sched = cosine_schedule(timesteps)
+        sched = self.sched = cosine_schedule(timesteps)
         dv = lambda x: x.to(self.device).contiguous()
         self.sqrt_ac, self.sqrt_1mac = dv(sched["sqrt_alphas_cumprod"]), dv(sched["sqrt_one_minus_alphas_cumprod"])
         self.time_table = dv(_time_table(timesteps))
@@ -263,6 +263,14 @@ class PriorTrainer:
     def refresh(self):
         for lin in self.lins:
             lin.refresh_transposed()
+
+    def reload_planes(self):
+        """Rebuild every derived copy of the parameters (bf16 hi/lo planes, transposed planes) after the flat fp32
+        buffer was written from outside (checkpoint resume)."""
+        S = self.store
+        L.check(L.load().avi_pack_weight_split(S.P.data_ptr(), 1, S.numel, 1, S.HI.data_ptr(), S.LO.data_ptr(),
+                                               L.stream_ptr()), "pack")
+        self.refresh()
 
     def _ln(self, x, g, b=None, act=ops.ACT_NONE, mask=None, residual=None, stable=0):
         S = self.store

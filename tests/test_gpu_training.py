@@ -110,3 +110,57 @@ def test_train_step_updates_parameters(gpu, setup):
     # a second step runs on the refreshed bf16 planes / transposed packs and keeps the loss finite
     out = tr.train_step(voxel.to(gpu), target.to(gpu), setup["temp"], rand=rand)
     assert torch.isfinite(out["loss_prior"]).all() and torch.isfinite(out["loss_nce"]).all()
+
+
+def test_checkpoint_round_trip_and_flame_pkl(gpu, tmp_path):
+    """{best,last}.pth in the reference's layout (train_diffusion_prior.py:155-168,238-251): resuming reproduces the
+    uninterrupted run (up to the float-atomic accumulation order of dnull_kv / drel_bias, ~1e-8), and the optimizer
+    part loads into a real torch.optim.AdamW built like :997-1004."""
+    import pickle
+    from avi_talking_amd.weights import make_prior_weights
+    from avi_talking_amd.host.training import PriorTrainer
+    from avi_talking_amd.host import checkpoint as CK
+    wp = make_prior_weights(3)
+    names = [k for k, v in wp.items() if v.is_floating_point() and not k.startswith("noise_scheduler")]
+    B = 64
+    g = torch.Generator(device=gpu).manual_seed(7)
+    voxel = torch.randn(B, 768, device=gpu, generator=g)
+    target = torch.randn(B, 1, 128, device=gpu, generator=g) * 0.3
+
+    def run(tr, rands):
+        return [tr.train_step(voxel, target, 0.005, rand=r)["loss_prior"].item() for r in rands]
+
+    tr = PriorTrainer(wp, device=gpu, lr=1e-3)
+    rands = [tr.draw(B, generator=g) for _ in range(4)]
+    run(tr, rands[:2])
+    path = CK.save_ckpt("last", str(tmp_path), 3, tr, names, losses=[1.0, 0.9], lrs=[1e-3])
+    tail_ref = run(tr, rands[2:])
+    ref_params = tr.store.P.clone()
+
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "lr_scheduler", "train_losses",
+                       "val_losses", "lrs"}
+    assert all(n in ck["model_state_dict"] for n in names)
+    assert len(ck["optimizer_state_dict"]["param_groups"]) == 4
+    # a torch AdamW built the reference's way accepts the optimizer state
+    params = {n: torch.nn.Parameter(ck["model_state_dict"][n].clone()) for n in names}
+    groups = CK.param_groups(names)
+    opt = torch.optim.AdamW([{"params": [params[n] for n in gn], "weight_decay": wd}
+                             for gn, wd in zip(groups, (1e-2, 0.0, 1e-2, 0.0))], lr=1e-3)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert float(opt.state[params[groups[2][0]]]["step"]) == 2.0
+
+    tr2 = PriorTrainer(make_prior_weights(99), device=gpu, lr=5e-4)       # different weights and lr: all overwritten
+    assert CK.resume_ckpt(path, tr2, names) == 3
+    assert tr2.step_count == 2 and tr2.lr == 1e-3
+    tail = run(tr2, rands[2:])
+    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(tail, tail_ref)), (tail, tail_ref)
+    worst = max(((tr2.store.view(n) - ref_params[tr.store.offset[n]:tr.store.offset[n] + tr.store.view(n).numel()]
+                  .view(tr.store.shape[n])).abs().max().item(), n) for n in names)
+    assert worst[0] < 1e-6, worst
+
+    fp = CK.save_flame_pkl(str(tmp_path / "flame" / "flame_x.pkl"), torch.zeros(300), torch.ones(5, 50), torch.ones(5, 3))
+    with open(fp, "rb") as f:
+        d = pickle.load(f)
+    assert set(d) == {"shape", "expression", "jaw_pose", "global_pose"} and d["global_pose"].shape == (5, 3)
+    assert not d["global_pose"].any()
