@@ -566,3 +566,17 @@ extern "C" int avi_attention_d64_planes(const float* qkv, int B, int H, int T, i
     return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, 0, nullptr, 1,
                             static_cast<hipStream_t>(stream), out_hi, out_lo);
 }
+
+// The same with the bias modes of avi_attention (2 with zero slopes = the plain causal mask of the CLIP text model).
+extern "C" int avi_attention_d64_planes_biased(const float* qkv, int B, int H, int T, int ld, float scale,
+                                               int bias_mode, const float* slopes, int period, float* out,
+                                               uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+    if (!qkv || !out_hi || !out_lo || B <= 0 || H <= 0 || T <= 0 || (ld & 3) || (ldo & 3)) return AVI_EINVAL;
+    if (ld < 3 * H * HD || ldo < H * HD || (long long)B * H > 65535) return AVI_EINVAL;
+    if (bias_mode < 0 || bias_mode > 2 || (bias_mode != 0 && !slopes) || period < 1) return AVI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+        ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 7))
+        return AVI_EINVAL;
+    return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, bias_mode, slopes,
+                            period, static_cast<hipStream_t>(stream), out_hi, out_lo);
+}

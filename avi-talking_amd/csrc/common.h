@@ -48,6 +48,7 @@ __device__ __forceinline__ float avi_act(float x, int act) {
         case AVI_ACT_LRELU02: return x > 0.f ? x : 0.2f * x;
         case AVI_ACT_RELU: return x > 0.f ? x : 0.f;
         case AVI_ACT_SILU: return x / (1.0f + __expf(-x));
+        case AVI_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
         default: return x;
     }
 }

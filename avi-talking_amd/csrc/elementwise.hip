@@ -464,6 +464,29 @@ __global__ void add_rowbcast_kernel(const float* __restrict__ in, const float* _
     }
 }
 
+// CLIPTextEmbeddings: out[b][t][:] = table[ids[b][t]][:] + pos[t][:]  (one float4 per thread; an id outside the table
+// is clamped - no fault - and counted so that the host can raise what nn.Embedding would have raised)
+__global__ void embed_tokens_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                    const float* __restrict__ pos, int B, int T, int C, int vocab,
+                                    float* __restrict__ out, int* __restrict__ bad_ids) {
+    const int v4 = C >> 2;
+    const long long total = (long long)B * T * v4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % v4);
+        const long long row = i / v4;
+        const int t = (int)(row % T);
+        long long id = ids[row];
+        if (id < 0 || id >= vocab) {
+            if (cv == 0 && bad_ids) atomicAdd(bad_ids, 1);
+            id = id < 0 ? 0 : vocab - 1;
+        }
+        const float4 a = reinterpret_cast<const float4*>(table + id * C)[cv];
+        const float4 d = reinterpret_cast<const float4*>(pos + (long long)t * C)[cv];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+    }
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 8192) {
     long long g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -608,5 +631,14 @@ extern "C" int avi_add_rowbcast(const float* in, const float* add, int B, int T,
     const long long total = (long long)B * T * (C >> 2);
     hipLaunchKernelGGL(add_rowbcast_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        in, add, B, T, C, out);
+    return avi_launch_status();
+}
+
+extern "C" int avi_embed_tokens(const long long* ids, const float* table, const float* pos, int B, int T, int C,
+                                int vocab, float* out, int* bad_ids, void* stream) {
+    if (!ids || !table || !pos || !out || B <= 0 || T <= 0 || C <= 0 || (C & 3) || vocab <= 0) return AVI_EINVAL;
+    const long long total = (long long)B * T * (C >> 2);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       ids, table, pos, B, T, C, vocab, out, bad_ids);
     return avi_launch_status();
 }

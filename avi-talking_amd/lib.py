@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libavi_talking_hip.so")
 
-ACT_NONE, ACT_GELU, ACT_LRELU02, ACT_RELU, ACT_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_LRELU02, ACT_RELU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 PREC_BF16, PREC_BF16X3 = 1, 3
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -88,9 +88,11 @@ SIGNATURES = {
     "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "avi_embed_tokens": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
     "avi_attention_d64_planes": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
+    "avi_attention_d64_planes_biased": [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],

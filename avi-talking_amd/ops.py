@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_RELU, ACT_SILU, PREC_BF16, PREC_BF16X3  # noqa: F401
+from .lib import (ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, PREC_BF16,  # noqa: F401
+                  PREC_BF16X3)
 
 
 def _f32c(t, name):
@@ -231,6 +232,22 @@ def add_rowbcast(x, add):
     return out
 
 
+def embed_tokens(ids, table, pos, bad_ids=None):
+    """(B, T) int64 token ids -> table[ids] + pos[:T]  (CLIPTextEmbeddings)."""
+    L.require_gpu(ids, table, pos)
+    if ids.dtype != torch.int64 or ids.dim() != 2 or not ids.is_contiguous():
+        raise ValueError("embed_tokens: ids must be a contiguous (B, T) int64 tensor")
+    B, T = ids.shape
+    vocab, Cc = table.shape
+    if pos.shape[0] < T or pos.shape[1] != Cc:
+        raise ValueError("embed_tokens: position table does not cover the sequence")
+    out = torch.empty((B, T, Cc), dtype=torch.float32, device=ids.device)
+    L.check(L.load().avi_embed_tokens(ids.data_ptr(), _f32c(table, "table").data_ptr(), _f32c(pos, "pos").data_ptr(),
+                                      B, T, Cc, vocab, out.data_ptr(), L.ptr(bad_ids), L.stream_ptr()),
+            "avi_embed_tokens")
+    return out
+
+
 def attention(q, k, v, H, D, ldq, ldk, Tq, Tk, B, scale, bias_mode=0, slopes=None, period=1, out=None):
     """q/k/v are base tensors (possibly views into one packed QKV buffer); ldq/ldk are row strides."""
     L.require_gpu(q, k, v)
@@ -257,15 +274,22 @@ def attention_d64(qkv, H, scale, out=None):
     return out
 
 
-def attention_d64_planes(qkv, H, scale):
+def attention_d64_planes(qkv, H, scale, bias_mode=0, slopes=None, period=1):
     """Head-dim-64 attention whose result is written as split planes (operand of the out_proj GEMM)."""
     qkv = _f32c(qkv, "qkv")
     B, T, ld = qkv.shape
     if ld != 3 * H * 64:
         raise ValueError(f"attention_d64_planes: last dim {ld} != 3*H*64")
     out = Planes((B, T, H * 64), qkv.device)
-    L.check(L.load().avi_attention_d64_planes(qkv.data_ptr(), B, H, T, ld, scale, None, out.hi.data_ptr(),
-                                              out.lo.data_ptr(), H * 64, L.stream_ptr()), "avi_attention_d64_planes")
+    if bias_mode == 0:
+        L.check(L.load().avi_attention_d64_planes(qkv.data_ptr(), B, H, T, ld, scale, None, out.hi.data_ptr(),
+                                                  out.lo.data_ptr(), H * 64, L.stream_ptr()),
+                "avi_attention_d64_planes")
+    else:
+        L.require_gpu(slopes)
+        L.check(L.load().avi_attention_d64_planes_biased(qkv.data_ptr(), B, H, T, ld, scale, bias_mode, L.ptr(slopes),
+                                                         period, None, out.hi.data_ptr(), out.lo.data_ptr(), H * 64,
+                                                         L.stream_ptr()), "avi_attention_d64_planes_biased")
     return out
 
 

@@ -221,3 +221,22 @@ def make_flame_basis(seed=4, n_vertices=5023, n_shape=300, n_exp=50):
     lw = lw / lw.sum(1, keepdim=True)
     return {"v_template": v_template, "shapedirs": shapedirs, "posedirs": posedirs, "J_regressor": Jr,
             "lbs_weights": lw, "parents": torch.tensor([-1, 0, 1, 1, 1], dtype=torch.long)}
+
+
+# ----------------------------------------------------------------------------- CLIP text encoder (the text branch)
+def make_clip_text_weights(seed=5, vocab=49408, hidden=768, ffn=3072, layers=12, max_pos=77):
+    """HF ``CLIPTextModel`` state_dict names for openai/clip-vit-large-patch14's text tower
+    (``FrozenCLIPEmbedder`` models/diffusion_prior.py:29-55)."""
+    I = _Init(seed)
+    I.normal("text_model.embeddings.token_embedding.weight", (vocab, hidden), 0.02)
+    I.normal("text_model.embeddings.position_embedding.weight", (max_pos, hidden), 0.01)
+    for l in range(layers):
+        p = f"text_model.encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            I.linear(p + "self_attn." + n, hidden, hidden, scale=1.7)
+        I.norm(p + "layer_norm1", hidden)
+        I.linear(p + "mlp.fc1", ffn, hidden, scale=1.7)
+        I.linear(p + "mlp.fc2", hidden, ffn, scale=1.7)
+        I.norm(p + "layer_norm2", hidden)
+    I.norm("text_model.final_layer_norm", hidden)
+    return I.w

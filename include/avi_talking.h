@@ -36,6 +36,7 @@ extern "C" {
 #define AVI_ACT_LRELU02 2 /* LeakyReLU(0.2) (L2lMotionPrior.py:376,389) */
 #define AVI_ACT_RELU 3    /* nn.TransformerDecoderLayer default (models/faceformer.py:148) */
 #define AVI_ACT_SILU 4
+#define AVI_ACT_QUICK_GELU 5 /* x*sigmoid(1.702x): CLIP text model hidden_act (models/diffusion_prior.py:29-55) */
 
 /* precision codes: how fp32 operands are fed to the bf16 matrix cores */
 #define AVI_PREC_BF16 1   /* x,w rounded to bf16; 1 MFMA per product; ~4e-3 relative */
@@ -140,6 +141,12 @@ int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, flo
 int avi_pad_repeat(const float* in, int B, int T, int C, int rep, int padL, int padR, int mode,
                    float* out, void* stream);
 
+/* out[b][t][c] = table[ids[b][t]][c] + pos[t][c]: CLIPTextEmbeddings (token + position embedding) under
+ * FrozenCLIPEmbedder.forward (models/diffusion_prior.py:48-53).  ids int64 [B][T], every id in [0, vocab) (an id out
+ * of range is clamped into the table and counted in *bad_ids, int32 device, caller-zeroed, may be NULL). */
+int avi_embed_tokens(const long long* ids, const float* table, const float* pos, int B, int T, int C, int vocab,
+                     float* out, int* bad_ids, void* stream);
+
 /* out[b][t][c] = in[b][t][c] + add[b][c]  (EMOTE style_op "add", FaceFormerDecoder.py:667-668) */
 int avi_add_rowbcast(const float* in, const float* add, int B, int T, int C, float* out, void* stream);
 
@@ -165,6 +172,11 @@ int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, float scale
  * the activation format of the LDS-DMA GEMMs, so encoder.layers.*.attention.out_proj reads it without conversion. */
 int avi_attention_d64_planes(const float* qkv, int B, int H, int T, int ld, float scale, float* out,
                              uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+/* Same, under the bias modes of avi_attention (slopes [H] device for modes 1, 2).  Mode 2 with zero slopes and
+ * period 1 is the causal mask of the CLIP text transformer behind FrozenCLIPEmbedder (models/diffusion_prior.py:52-53). */
+int avi_attention_d64_planes_biased(const float* qkv, int B, int H, int T, int ld, float scale, int bias_mode,
+                                    const float* slopes, int period, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                    int ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion prior.  Replaces VersatileDiffusionPriorNetwork.forward (models/diffusion_prior.py:223-313),

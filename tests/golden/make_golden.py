@@ -218,12 +218,38 @@ def gen_flame():
     print("flame.npz: verts", tuple(v.shape), "slice", tuple(v[:, idx].shape))
 
 
+def gen_clip_text():
+    """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
+    openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                         num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                         layer_norm_eps=1e-5)
+    model = CLIPTextModel(cfg).eval()
+    w = W.make_clip_text_weights(5)
+    keys = set(model.state_dict().keys())             # this transformers drops the "text_model." prefix
+    print(model.load_state_dict({(k if k in keys else k[len("text_model."):]): v for k, v in w.items()}, strict=True))
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, 49406, (3, 77), generator=g)
+    ids[:, 0] = 49406                                  # <|startoftext|>
+    for b, n in enumerate((9, 30, 76)):                # <|endoftext|> then padding with it (padding="max_length")
+        ids[b, n:] = 49407
+    with torch.no_grad():
+        out = model(input_ids=ids).last_hidden_state
+        short = model(input_ids=ids[:1, :20].contiguous()).last_hidden_state
+    np.savez_compressed(os.path.join(HERE, "clip_text.npz"), ids=ids.numpy(), out_shape=np.array(out.shape),
+                        out_slice=out[:, :, ::8].numpy(), out_sum=out.double().sum((1, 2)).numpy(),
+                        short_slice=short[0, :, ::8].numpy())
+    print("clip_text.npz:", tuple(out.shape))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "flame":      # regenerate only the FLAME fixture
-        gen_flame()
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text"):      # regenerate only one fixture
+        {"flame": gen_flame, "clip_text": gen_clip_text}[sys.argv[1]]()
         sys.exit(0)
     gen_flame()
+    gen_clip_text()
     gen_wav2vec2()
     ff, dp = import_reference_models()
     gen_masks(ff)

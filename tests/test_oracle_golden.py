@@ -95,3 +95,36 @@ def test_flame_lbs_matches_reference_lbs():
     err = (v[:, torch.from_numpy(g["vidx"])] - t("verts")).abs().max().item()
     assert err < 1e-6, err
     assert np.abs(v.double().sum((1, 2)).numpy() - g["vsum"]).max() < 1e-4
+
+
+def test_clip_text_oracle_matches_transformers_golden():
+    """oracle/clip_text.py against transformers.CLIPTextModel outputs on the seeded weights
+    (tests/golden/clip_text.npz: the class FrozenCLIPEmbedder wraps, models/diffusion_prior.py:40,52-53)."""
+    from oracle import clip_text as OC
+    g = _load("clip_text.npz")
+    w = W.make_clip_text_weights(5)
+    ids = torch.from_numpy(g["ids"])
+    out = OC.clip_text_forward(w, ids)
+    assert list(out.shape) == list(g["out_shape"])
+    assert np.abs(out[:, :, ::8].numpy() - g["out_slice"]).max() < 2e-5
+    assert np.allclose(out.double().sum((1, 2)).numpy(), g["out_sum"], atol=2e-3)
+    short = OC.clip_text_forward(w, ids[:1, :20].contiguous())
+    assert np.abs(short[0, :, ::8].numpy() - g["short_slice"]).max() < 2e-5
+
+
+def test_clip_text_oracle_matches_transformers_live():
+    """Same pin against the installed transformers class itself (skipped where transformers has no CLIP)."""
+    tr = pytest.importorskip("transformers")
+    from oracle import clip_text as OC
+    cfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                            num_attention_heads=4, max_position_embeddings=77, hidden_act="quick_gelu",
+                            layer_norm_eps=1e-5)
+    torch.manual_seed(3)
+    m = tr.CLIPTextModel(cfg).eval()
+    sd = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in m.state_dict().items()
+          if v.is_floating_point()}
+    ids = torch.randint(0, 1000, (2, 33), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = m(input_ids=ids).last_hidden_state
+    out = OC.clip_text_forward(sd, ids, layers=2, heads=4)
+    assert (out - ref).abs().max().item() < 2e-5
