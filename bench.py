@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--secondary-timeout", type=float, default=300.0,
+                    help="seconds the roofline / cpu_baseline / flame / train legs may take before the line is printed "
+                         "without them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,41 +125,56 @@ def main():
     frames = world * B_CLIPS * T_FRAMES * args.steps
     value = frames / dt
 
-    roofline = cpu_baseline = None
-    if rank == 0:
-        roofline = measure_gemm_roofline(pipe, pcm, voxel, noise, prec)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = measure_cpu_baseline(wa, wh, wp)
-    del pipe
-    torch.cuda.empty_cache()
-    flame = None
-    if rank == 0 and not args.no_train:
-        try:
-            flame = measure_flame(dev)
-        except Exception as e:
-            flame = {"error": f"{type(e).__name__}: {e}"[:300]}
-    train = None
-    if not args.no_train:
-        try:
-            train = measure_train(wp, dev, world, rank, local_rank, dist, args)
-        except Exception as e:  # the sampling line above must survive a failure of the secondary measurement
-            train = {"error": f"{type(e).__name__}: {e}"[:300]}
+    line = {
+        "metric": "expression-frames/sec (sampling: audio+text -> FLAME exp/jaw coefficients)",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+        "config": {"workload": "configs[1]: 32 clips x 10 s @16 kHz per GPU -> 250 frames @25 fps each; "
+                               "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
+                   "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
+                   "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
+        "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
+        "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
+        "roofline": None, "cpu_baseline": None, "train": None, "flame": None,
+    }
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        # a secondary measurement hung (the training leg is the only one with collectives): the sampling line,
+        # already measured, must still come out, and no rank may be left behind holding the GPU
+        if line["train"] is None:
+            line["train"] = {"error": f"secondary measurements exceeded {args.secondary_timeout} s"}
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    timer = threading.Timer(args.secondary_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
 
     if rank == 0:
-        line = {
-            "metric": "expression-frames/sec (sampling: audio+text -> FLAME exp/jaw coefficients)",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "configs[1]: 32 clips x 10 s @16 kHz per GPU -> 250 frames @25 fps each; "
-                                   "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
-                       "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
-                       "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
-            "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
-            "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "train": train, "flame": flame,
-        }
-        print(json.dumps(line), flush=True)
+        line["roofline"] = measure_gemm_roofline(pipe, pcm, voxel, noise, prec)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = measure_cpu_baseline(wa, wh, wp)
+    del pipe
+    torch.cuda.empty_cache()
+    if rank == 0 and not args.no_train:
+        try:
+            line["flame"] = measure_flame(dev)
+        except Exception as e:
+            line["flame"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if not args.no_train:
+        try:
+            line["train"] = measure_train(wp, dev, world, rank, local_rank, dist, args)
+        except Exception as e:  # the sampling line above must survive a failure of the secondary measurement
+            line["train"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    timer.cancel()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 
