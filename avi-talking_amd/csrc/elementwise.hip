@@ -487,6 +487,17 @@ __global__ void embed_tokens_kernel(const long long* __restrict__ ids, const flo
     }
 }
 
+// out[b][c] = mean over t of in[b][t][c]; one thread per (b, c), consecutive threads on consecutive channels
+__global__ void mean_tokens_kernel(const float* __restrict__ in, int B, int T, int C, float* __restrict__ out) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    const float* p = in + (long long)b * T * C + c;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += p[(long long)t * C];
+    out[i] = s / (float)T;
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 8192) {
     long long g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -640,5 +651,13 @@ extern "C" int avi_embed_tokens(const long long* ids, const float* table, const 
     const long long total = (long long)B * T * (C >> 2);
     hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        ids, table, pos, B, T, C, vocab, out, bad_ids);
+    return avi_launch_status();
+}
+
+extern "C" int avi_mean_tokens(const float* in, int B, int T, int C, float* out, void* stream) {
+    if (!in || !out || B <= 0 || T <= 0 || C <= 0) return AVI_EINVAL;
+    const long long total = (long long)B * C;
+    hipLaunchKernelGGL(mean_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, B, T, C, out);
     return avi_launch_status();
 }

@@ -52,12 +52,26 @@ __global__ void transpose_pack_kernel(const float* __restrict__ in, int R, int C
     }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ in, int R, int Cc, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cc) return;
+// block = 16 columns x 16 row groups: the rows of a column are walked by 16 threads and met in LDS in a fixed order
+// (one thread per column walking all rows serially took 15-20 us per call for 64..256 rows: pure load latency)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int Cc,
+                                                      float* __restrict__ out, int accumulate) {
+    __shared__ float ps[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += in[(long long)r * Cc + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < Cc) {
+#pragma unroll 4
+        for (int r = ty; r < R; r += 16) s += in[(long long)r * Cc + c];
+    }
+    ps[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < Cc) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += ps[j][tx];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ------------------------------------------------------------------ activations
@@ -208,8 +222,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 }
 
 // dgamma[c] (+)= sum_r dy*mask*act'(u)*xhat ;  dbeta[c] (+)= sum_r dy*mask*act'(u)
-// block = 64 columns x 4 row groups (a serial walk over the rows by one thread per column cost 50 us per call, 18 % of
-// the training step); partial sums meet in LDS in a fixed order, so the result is deterministic.
+// block = 16 columns x 16 row groups (a serial walk over the rows by one thread per column cost 50 us per call, 18 % of
+// the training step; 64 x 4 still left 64 dependent row visits per thread); partial sums meet in LDS in a fixed order,
+// so the result is deterministic.
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
@@ -217,14 +232,14 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
                                                              const float* __restrict__ stats, int rows, int C, int act,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int accumulate) {
-    __shared__ float pg[4][64], pb[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    __shared__ float pg[16][17], pb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     float sg = 0.f, sb = 0.f;
     if (c < C) {
         const float g = gamma[c], b = beta ? beta[c] : 0.f;
 #pragma unroll 4
-        for (int r = ty; r < rows; r += 4) {
+        for (int r = ty; r < rows; r += 16) {
             const float mean = stats[r * 3], rstd = stats[r * 3 + 1], pre = stats[r * 3 + 2];
             const float xh = (x[(long long)r * C + c] * pre - mean) * rstd;
             const float t =
@@ -237,8 +252,12 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
     pb[ty][tx] = sb;
     __syncthreads();
     if (ty == 0 && c < C) {
-        sg = (pg[0][tx] + pg[1][tx]) + (pg[2][tx] + pg[3][tx]);
-        sb = (pb[0][tx] + pb[1][tx]) + (pb[2][tx] + pb[3][tx]);
+        sg = sb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sg += pg[j][tx];
+            sb += pb[j][tx];
+        }
         dgamma[c] = accumulate ? dgamma[c] + sg : sg;
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
     }
@@ -632,7 +651,7 @@ extern "C" int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pa
 
 extern "C" int avi_colsum(const float* in, int R, int Cc, float* out, int accumulate, void* stream) {
     if (!in || !out || R <= 0 || Cc <= 0) return AVI_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((Cc + 255) / 256), dim3(256), 0, S_(stream), in, R, Cc, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((Cc + 15) / 16), dim3(256), 0, S_(stream), in, R, Cc, out, accumulate);
     return avi_launch_status();
 }
 
@@ -670,7 +689,7 @@ extern "C" int avi_layernorm_bwd(const float* x, const float* dy, const float* g
     else
         hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, s, x, dy, gamma, beta, mask, rows, C, eps, act, stable,
                            dx_add, dx, stats);
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, dy, gamma, beta, mask, stats,
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 15) / 16), dim3(256), 0, s, x, dy, gamma, beta, mask, stats,
                        rows, C, act, dgamma, dbeta, accumulate);
     return avi_launch_status();
 }

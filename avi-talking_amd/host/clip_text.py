@@ -101,3 +101,36 @@ class FrozenCLIPEmbedder:
 
     def encode(self, text):    # models/diffusion_prior.py:54-55
         return self(text)
+
+    def voxel(self, text):
+        """``clip_extractor(text).mean(dim=1)`` (train_diffusion_prior.py:438-439,710-711): the (B, hidden) text
+        feature the aligner (``voxel2clip``) consumes."""
+        return ops.mean_tokens(self(text))
+
+    # ---- hipGraph of one forward at a fixed (B, T): ~90 launches replayed as one submission
+    def capture(self, input_ids, warmup=2):
+        if input_ids.dtype != torch.int64 or input_ids.dim() != 2:
+            raise ValueError("input_ids must be a (B, T) int64 tensor")
+        self._ids = input_ids.to(self.device).contiguous().clone()
+        for _ in range(warmup):
+            self.encode_ids(self._ids)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            h = self.encode_ids(self._ids)
+            self._out = (h, ops.mean_tokens(h))
+        return self
+
+    def replay(self, input_ids=None):
+        """-> (last_hidden_state, voxel) of the captured shape; ids on the host are range-checked as in forward."""
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("capture() first")
+        if input_ids is not None:
+            if tuple(input_ids.shape) != tuple(self._ids.shape) or input_ids.dtype != torch.int64:
+                raise ValueError("replay: input_ids must match the captured shape and dtype")
+            if not input_ids.is_cuda and input_ids.numel() and (
+                    int(input_ids.min()) < 0 or int(input_ids.max()) >= self.tok.shape[0]):
+                raise IndexError("index out of range in self")
+            self._ids.copy_(input_ids, non_blocking=True)
+        self._graph.replay()
+        return self._out

@@ -78,11 +78,21 @@ class _Lin:
                                              L.ptr(residual), y.data_ptr(), L.stream_ptr()), "avi_splitk_epilogue")
         return y
 
+    @staticmethod
+    def _use_skinny(M, N, K):
+        """A few row tiles and a long K: one or two workgroups per column tile walking 8..64 K tiles are pure latency
+        (40 us for the 256 x 128 x 1024 dX of the prior's feed-forward); K slices spread the walk over the chip."""
+        return M <= 256 and K >= 512 and K % 128 == 0 and N % 4 == 0 and N <= 4096
+
+    @staticmethod
+    def _kslice(K):
+        return 256 if K >= 2048 and K % 256 == 0 else 128
+
     def fwd(self, x, act=ops.ACT_NONE):
         M = x.numel() // self.K
-        if M <= 128 and self.K >= 1024 and self.K % 256 == 0 and self.N % 4 == 0 and self.N <= 4096:
+        if self._use_skinny(M, self.N, self.K):
             return self._skinny(x, self.K, self.s.hi_ptr(self.w), self.s.lo_ptr(self.w), M, self.N, self.K,
-                                bias=self.s.ptr(self.b) if self.b else 0, act=act)
+                                bias=self.s.ptr(self.b) if self.b else 0, act=act, kslice=self._kslice(self.K))
         y = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
         ops.gemm_raw(A=x.data_ptr(), lda=self.K, Whi=self.s.hi_ptr(self.w), Wlo=self.s.lo_ptr(self.w), C_=y.data_ptr(),
                      ldc=self.N, M=M, N=self.N, K=self.K, bias=self.s.ptr(self.b) if self.b else 0, act=act)
@@ -108,9 +118,9 @@ class _Lin:
             L.check(so.avi_colsum(dy.data_ptr(), M, self.N, self.s.gptr(self.b), 0, L.stream_ptr()), "colsum")
         if not self.need_dx:
             return None
-        if M <= 128 and self.N >= 1024 and self.N % 256 == 0 and self.K % 4 == 0 and self.K <= 4096:
+        if self._use_skinny(M, self.K, self.N):
             return self._skinny(dy, self.N, self.hiT.data_ptr(), self.loT.data_ptr(), M, self.K, self.N,
-                                residual=dx_residual)
+                                residual=dx_residual, kslice=self._kslice(self.N))
         dx = torch.empty((M, self.K), dtype=torch.float32, device=dev)
         ops.gemm_raw(A=dy.data_ptr(), lda=self.N, Whi=self.hiT.data_ptr(), Wlo=self.loT.data_ptr(), C_=dx.data_ptr(),
                      ldc=self.K, M=M, N=self.K, K=self.N, R=L.ptr(dx_residual), ldr=self.K)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "avi_embed_tokens": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "avi_mean_tokens": [_vp, _i, _i, _i, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
     "avi_attention_d64_planes": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],

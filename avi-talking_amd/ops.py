@@ -248,6 +248,15 @@ def embed_tokens(ids, table, pos, bad_ids=None):
     return out
 
 
+def mean_tokens(x):
+    """(B, T, C) -> (B, C) mean over T."""
+    x = _f32c(x, "x")
+    B, T, Cc = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.load().avi_mean_tokens(x.data_ptr(), B, T, Cc, out.data_ptr(), L.stream_ptr()), "avi_mean_tokens")
+    return out
+
+
 def attention(q, k, v, H, D, ldq, ldk, Tq, Tk, B, scale, bias_mode=0, slopes=None, period=1, out=None):
     """q/k/v are base tensors (possibly views into one packed QKV buffer); ldq/ldk are row strides."""
     L.require_gpu(q, k, v)

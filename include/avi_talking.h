@@ -146,6 +146,9 @@ int avi_pad_repeat(const float* in, int B, int T, int C, int rep, int padL, int 
  * of range is clamped into the table and counted in *bad_ids, int32 device, caller-zeroed, may be NULL). */
 int avi_embed_tokens(const long long* ids, const float* table, const float* pos, int B, int T, int C, int vocab,
                      float* out, int* bad_ids, void* stream);
+/* out[b][c] = mean_t in[b][t][c]: the caller's pooling of the text feature, `CLIP(text).mean(dim=1)`
+ * (train_diffusion_prior.py:438-439,710-711), which yields the (B,768) voxel the aligner consumes. */
+int avi_mean_tokens(const float* in, int B, int T, int C, float* out, void* stream);
 
 /* out[b][t][c] = in[b][t][c] + add[b][c]  (EMOTE style_op "add", FaceFormerDecoder.py:667-668) */
 int avi_add_rowbcast(const float* in, const float* add, int B, int T, int C, float* out, void* stream);

@@ -61,6 +61,25 @@ def test_clip_text_is_causal_and_batch_independent(gpu, embedder):
     assert (single[0] - base[2]).abs().max().item() < 1e-5
 
 
+def test_clip_text_voxel_and_graph_replay(gpu, embedder, clip_w):
+    """The pooled (B,768) text feature, and a captured forward replayed on new ids (bit-equal to the eager pass)."""
+    from oracle import clip_text as OC
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(0, 49408, (4, 77), generator=g)
+    ref = OC.clip_text_forward(clip_w, ids).mean(dim=1)             # train_diffusion_prior.py:438-439
+    vox = embedder.voxel(ids)
+    assert vox.shape == (4, 768)
+    assert (vox.cpu() - ref).abs().max().item() < TOL
+    embedder.capture(torch.zeros((4, 77), dtype=torch.int64))
+    h, v = embedder.replay(ids)
+    assert torch.equal(h, embedder(ids)) and torch.equal(v, vox)
+    ids2 = torch.randint(0, 49408, (4, 77), generator=g)
+    h2, _ = embedder.replay(ids2)
+    assert torch.equal(h2, embedder(ids2))
+    with pytest.raises(ValueError):
+        embedder.replay(ids[:2])
+
+
 def test_clip_text_rejects_bad_input(gpu, embedder):
     with pytest.raises(IndexError):
         embedder(torch.full((1, 77), 49408, dtype=torch.int64))
