@@ -11,7 +11,12 @@
 //   per (frame, vertex) (flame_vertices_kernel):
 //     v_posed  = v_shaped + sum_k exp_k E_k + sum_p feature_p P_p      (86 basis vectors, staged once per block in LDS)
 //     vertex   = (sum_j w_vj A_j) . [v_posed; 1]
-// flame_vertices_kernel: block = 128 vertices x all frames of one clip; 512 threads = 128 vertices x 4 frame
+// flame_vertices_mfma_kernel (the path taken when the basis planes are present): the 86-vector blend is a
+// [frames x 96] . [96 x V*3] product in 3-term split bf16 on the matrix cores, one wave per 16 vertices x all frames
+// of one clip with the basis fragments resident in registers; the skinning runs on the accumulators (a lane holds
+// x, y, z of 4 consecutive vertices of one frame) and the result leaves as 48 contiguous bytes per lane.
+// flame_vertices_kernel (fallback for bases wider than 160 vectors or without planes): all fp32 on the vector pipe,
+// block = 128 vertices x all frames of one clip; 512 threads = 128 vertices x 4 frame
 // subgroups, 8 frames in flight per thread (24 accumulators); per-frame coefficients are wave-uniform (scalar loads)
 // and stored frame-group-major [f/8][k][8] by flame_frame_kernel so that one 32-byte scalar load feeds 8 frames.
 #include "common.h"
@@ -20,30 +25,78 @@ namespace {
 
 constexpr int NJ = 5, NPF = 36, VT = 128, FG = 8;   // joints, pose features, vertices per block, frames per group
 
-__global__ __launch_bounds__(256) void flame_shape_kernel(const AviFlameBasis fb, const float* __restrict__ shape,
+constexpr int SC = 4;   // clips per thread of the shape pass: one basis load feeds SC accumulators
+
+// grid (ceil(V*3/256), ceil(B/SC)).  The k loop is unrolled by 4 so that four basis loads are in flight per thread.
+__global__ __launch_bounds__(256) void flame_shape_kernel(const AviFlameBasis fb, const float* __restrict__ shape, int B,
                                                            float* __restrict__ v_shaped) {
-    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, n = fb.V * 3;
+    const int b0 = blockIdx.y * SC, i = blockIdx.x * blockDim.x + threadIdx.x, n = fb.V * 3;
     if (i >= n) return;
-    float a = fb.v_template[i];
+    const float* sp[SC];     // wave-uniform rows of `shape` (scalar loads); clips past B repeat the last one
+#pragma unroll
+    for (int c = 0; c < SC; ++c) sp[c] = shape + (long long)(b0 + c < B ? b0 + c : B - 1) * fb.n_shape;
+    float a[SC];
+    const float t = fb.v_template[i];
+#pragma unroll
+    for (int c = 0; c < SC; ++c) a[c] = t;
+    const float* bp = fb.shape_basis + i;
+    int k = 0;
+    for (; k + 4 <= fb.n_shape; k += 4) {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = bp[(long long)(k + u) * n];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k + u], e[u], a[c]);
+    }
+    for (; k < fb.n_shape; ++k) {
+        const float e = bp[(long long)k * n];
+#pragma unroll
+        for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k], e, a[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < SC; ++c)
+        if (b0 + c < B) v_shaped[(long long)(b0 + c) * n + i] = a[c];
+}
+
+// jclip[b][15] = j_template + j_shape . shape[b]: the per-clip part of the joint regression, hoisted out of the frames.
+// One wave per clip; lanes split k.
+__global__ __launch_bounds__(64) void flame_joints_kernel(const AviFlameBasis fb, const float* __restrict__ shape,
+                                                           float* __restrict__ jclip) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     const float* sp = shape + (long long)b * fb.n_shape;
-    for (int k = 0; k < fb.n_shape; ++k) a = fmaf(sp[k], fb.shape_basis[(long long)k * n + i], a);
-    v_shaped[(long long)b * n + i] = a;
+    float a[NJ * 3];
+#pragma unroll
+    for (int j = 0; j < NJ * 3; ++j) a[j] = 0.f;
+    for (int k = lane; k < fb.n_shape; k += 64) {
+        const float x = sp[k];
+#pragma unroll
+        for (int j = 0; j < NJ * 3; ++j) a[j] = fmaf(fb.j_shape[(long long)j * fb.n_shape + k], x, a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ * 3; ++j) {
+        const float v = wave_sum_u(a[j]);
+        if (lane == 0) jclip[b * 16 + j] = fb.j_template[j] + v;
+    }
 }
 
 // frame record (floats): coefficients live in `coef` [F/8][K][8] (K = n_exp + 36), transforms in `xf` [F][5][12]
-__global__ __launch_bounds__(64) void flame_frame_kernel(const AviFlameBasis fb, const float* __restrict__ shape,
-                                                          const float* __restrict__ exp, const float* __restrict__ pose,
-                                                          int T, int F, float* __restrict__ coef,
-                                                          float* __restrict__ xf) {
-    __shared__ float J[NJ * 3], R[NJ * 9], A[NJ * 16];
-    const int f = blockIdx.x, lane = threadIdx.x, b = f / T;
+// one wave per frame, four frames per block
+__global__ __launch_bounds__(256) void flame_frame_kernel(const AviFlameBasis fb, const float* __restrict__ jclip,
+                                                           const float* __restrict__ exp, const float* __restrict__ pose,
+                                                           int T, int F, float* __restrict__ coef,
+                                                           float* __restrict__ xf, int KP) {
+    __shared__ float Js[4][NJ * 3], Rs[4][NJ * 9];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + wv < F ? blockIdx.x * 4 + wv : F - 1;   // a spare wave repeats the last frame
+    const int b = f / T;
+    float* J = Js[wv];
+    float* R = Rs[wv];
     const int K = fb.n_exp + NPF;
     const float* ef = exp + (long long)f * fb.n_exp;
     if (lane < NJ * 3) {   // joint coordinate `lane`
-        float a = fb.j_template[lane];
-        const float* js = fb.j_shape + (long long)lane * fb.n_shape;
-        const float* sp = shape + (long long)b * fb.n_shape;
-        for (int k = 0; k < fb.n_shape; ++k) a = fmaf(js[k], sp[k], a);
+        float a = jclip[b * 16 + lane];
         const float* je = fb.j_exp + (long long)lane * fb.n_exp;
         for (int k = 0; k < fb.n_exp; ++k) a = fmaf(je[k], ef[k], a);
         J[lane] = a;
@@ -63,14 +116,25 @@ __global__ __launch_bounds__(64) void flame_frame_kernel(const AviFlameBasis fb,
         for (int i = 0; i < 9; ++i) R[lane * 9 + i] = ((i % 4 == 0) ? 1.f : 0.f) + s * k1[i] + c1 * kk[i];
     }
     __syncthreads();
-    for (int k = lane; k < K; k += 64) {   // coefficients of the 86 basis vectors
-        float v;
+    // coefficients of the 86 basis vectors: fp32 frame-group-major for the vector-pipe kernel (KP == 0), or split
+    // bf16 planes [F][KP] hi | [F][KP] lo (zero beyond K) for the matrix-core kernel
+    uint16_t* chi = reinterpret_cast<uint16_t*>(coef);
+    uint16_t* clo = chi + (long long)F * KP;
+    for (int k = lane; k < (KP ? KP : K); k += 64) {
+        float v = 0.f;
         if (k < fb.n_exp) v = ef[k];
-        else {
+        else if (k < K) {
             const int q = k - fb.n_exp;   // (R[1 + q/9] - I).flat[q % 9]   (lbs.py:210)
             v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
         }
-        coef[((long long)(f / FG) * K + k) * FG + (f % FG)] = v;
+        if (KP) {
+            const __bf16 h = (__bf16)v;
+            const __bf16 l = (__bf16)(v - (float)h);
+            chi[(long long)f * KP + k] = __builtin_bit_cast(uint16_t, h);
+            clo[(long long)f * KP + k] = __builtin_bit_cast(uint16_t, l);
+        } else {
+            coef[((long long)(f / FG) * K + k) * FG + (f % FG)] = v;
+        }
     }
     if (lane == 0) {       // lbs.py:351-410, parents = [-1, 0, 1, 1, 1]
         float G[NJ][12];   // rows 0..2 of the chained transforms
@@ -111,7 +175,6 @@ __global__ __launch_bounds__(64) void flame_frame_kernel(const AviFlameBasis fb,
                 o[j * 12 + r * 4 + 3] = G[j][r * 4 + 3] - (G[j][r * 4 + 0] * J[j * 3] + G[j][r * 4 + 1] * J[j * 3 + 1] +
                                                            G[j][r * 4 + 2] * J[j * 3 + 2]);
             }
-        (void)A;
     }
 }
 
@@ -177,6 +240,117 @@ __global__ __launch_bounds__(512) void flame_vertices_kernel(const AviFlameBasis
     }
 }
 
+
+// ---- matrix-core path ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 48-byte runs of the output are dword aligned
+
+// basis planes [3][Vp][KP]: hi/lo[(c*Vp + v)*KP + k] = split of frame_basis[k][v*3 + c]; zero for v >= V, k >= K
+__global__ __launch_bounds__(256) void flame_pack_basis_kernel(const AviFlameBasis fb, int Vp, int KP,
+                                                                uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= 3LL * Vp * KP) return;
+    const int k = (int)(i % KP), v = (int)((i / KP) % Vp), c = (int)(i / ((long long)KP * Vp));
+    const int K = fb.n_exp + NPF;
+    const float x = (k < K && v < fb.V) ? fb.frame_basis[(long long)k * fb.V * 3 + v * 3 + c] : 0.f;
+    const __bf16 h = (__bf16)x;
+    hi[i] = __builtin_bit_cast(uint16_t, h);
+    lo[i] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+}
+
+// grid (ceil(V/64), B), block 256: wave w owns vertices [vt*16, vt*16+16), vt = 4*blockIdx.x + w, and walks the
+// frames of clip blockIdx.y in tiles of 16.  No LDS, no barriers (a wave past the last vertex tile just leaves).
+// MFMA operand roles as in gemm.hip: first operand = rows of the "n" matrix (vertices), second = rows of the "m"
+// matrix (frames); lane (fr, fq) receives D[frame f0+fr][vertex vt*16 + fq*4 + 0..3] per coordinate plane.
+template <int KS>
+__global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kernel(const AviFlameBasis fb,
+                                                                   const float* __restrict__ v_shaped,
+                                                                   const uint16_t* __restrict__ chi,
+                                                                   const uint16_t* __restrict__ clo,
+                                                                   const float* __restrict__ xf, int T, int Vp,
+                                                                   float* __restrict__ verts) {
+    constexpr int KP = KS * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int vt = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (vt * 16 >= fb.V) return;
+    bf16x8 bh[3][KS], bl[3][KS];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const long long o = ((long long)c * Vp + vt * 16 + fr) * KP + ks * 32 + fq * 8;
+            bh[c][ks] = *reinterpret_cast<const bf16x8*>(fb.basis_hi + o);
+            bl[c][ks] = *reinterpret_cast<const bf16x8*>(fb.basis_lo + o);
+        }
+    const int vb = vt * 16 + fq * 4, n3 = fb.V * 3;
+    float w[4][NJ], vs[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int vi = vb + j < fb.V ? vb + j : fb.V - 1;   // vertices past V: computed from a valid row, never stored
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) w[j][q] = fb.lbs_weights[(long long)vi * NJ + q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vs[j][c] = v_shaped[(long long)b * n3 + vi * 3 + c];
+    }
+    const int fbeg = b * T, fend = fbeg + T;
+    for (int f0 = fbeg; f0 < fend; f0 += 16) {
+        const int f = f0 + fr;
+        const int fc = f < fend ? f : fend - 1;          // rows past the clip are computed and dropped
+        f32x4 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const long long o = (long long)fc * KP + ks * 32 + fq * 8;
+            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(chi + o);
+            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(clo + o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[c][ks], ch, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c][ks], cl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c][ks], ch, acc[c], 0, 0, 0);
+            }
+        }
+        // skinning (lbs.py:215-235): the 5 x (3x4) transforms of this lane's frame, blended per vertex
+        // (row r of all five transforms at a time: 20 live registers instead of 60)
+        const f32x4* ap = reinterpret_cast<const f32x4*>(xf + (long long)fc * (NJ * 12));
+        float px[4], py[4], pz[4], o[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            px[j] = vs[j][0] + acc[0][j];
+            py[j] = vs[j][1] + acc[1][j];
+            pz[j] = vs[j][2] + acc[2][j];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x4 a[NJ];
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) a[q] = ap[q * 3 + r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 t = a[0] * w[j][0];
+#pragma unroll
+                for (int q = 1; q < NJ; ++q) t += a[q] * w[j][q];
+                o[j * 3 + r] = t[0] * px[j] + t[1] * py[j] + t[2] * pz[j] + t[3];
+            }
+        }
+        if (f < fend) {
+            float* op = verts + ((long long)f * fb.V + vb) * 3;
+            if (vb + 3 < fb.V) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    *reinterpret_cast<f32x4u*>(op + 4 * i) = (f32x4u){o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    if (vb + i / 3 < fb.V) op[i] = o[i];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int avi_flame_vertices(const AviFlameBasis* fbp, const float* shape, const float* exp, const float* pose,
@@ -187,19 +361,50 @@ extern "C" int avi_flame_vertices(const AviFlameBasis* fbp, const float* shape, 
         !fb.lbs_weights || fb.V <= 0 || fb.n_shape <= 0 || fb.n_exp <= 0)
         return AVI_EINVAL;
     const int K = fb.n_exp + NPF;
-    const int smem = K * 3 * VT * (int)sizeof(float);
-    if (smem > 160 * 1024) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int F = B * T;
+    float* jclip = xf + (long long)F * (NJ * 12);   // [B][16] behind the transforms
+    hipLaunchKernelGGL(flame_shape_kernel, dim3((fb.V * 3 + 255) / 256, (B + SC - 1) / SC), dim3(256), 0, s, fb, shape, B,
+                       v_shaped);
+    hipLaunchKernelGGL(flame_joints_kernel, dim3(B), dim3(64), 0, s, fb, shape, jclip);
+    if (fb.basis_hi && fb.basis_lo && K <= 160) {   // matrix-core path
+        if ((reinterpret_cast<uintptr_t>(fb.basis_hi) | reinterpret_cast<uintptr_t>(fb.basis_lo) |
+             reinterpret_cast<uintptr_t>(coef) | reinterpret_cast<uintptr_t>(xf)) & 15)
+            return AVI_EINVAL;
+        const int KS = K <= 96 ? 3 : 5, KP = KS * 32, Vp = (fb.V + 15) / 16 * 16;
+        hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, KP);
+        const uint16_t* chi = reinterpret_cast<const uint16_t*>(coef);
+        const uint16_t* clo = chi + (long long)F * KP;
+        const dim3 grid((Vp / 16 + 3) / 4, B);
+        if (KS == 3)
+            hipLaunchKernelGGL(flame_vertices_mfma_kernel<3>, grid, dim3(256), 0, s, fb, v_shaped, chi, clo, xf, T, Vp, verts);
+        else
+            hipLaunchKernelGGL(flame_vertices_mfma_kernel<5>, grid, dim3(256), 0, s, fb, v_shaped, chi, clo, xf, T, Vp, verts);
+        return avi_launch_status();
+    }
+    const int smem = K * 3 * VT * (int)sizeof(float);
+    if (smem > 160 * 1024) return AVI_EINVAL;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flame_vertices_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(flame_shape_kernel, dim3((fb.V * 3 + 255) / 256, B), dim3(256), 0, s, fb, shape, v_shaped);
-    hipLaunchKernelGGL(flame_frame_kernel, dim3(F), dim3(64), 0, s, fb, shape, exp, pose, T, F, coef, xf);
+    hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, 0);
     hipLaunchKernelGGL(flame_vertices_kernel, dim3((fb.V + VT - 1) / VT, B), dim3(512), smem, s, fb, v_shaped, coef, xf,
                        T, verts);
+    return avi_launch_status();
+}
+
+// Split bf16 planes of the per-frame basis for the matrix-core path: hi/lo [3][Vp][KP] uint16, Vp = V rounded up to 16,
+// KP = 96 for n_exp + 36 <= 96, else 160.  Run once per model; the caller stores the pointers in AviFlameBasis.
+extern "C" int avi_flame_pack_basis(const AviFlameBasis* fbp, uint16_t* hi, uint16_t* lo, void* stream) {
+    if (!fbp || !hi || !lo || !fbp->frame_basis || fbp->V <= 0 || fbp->n_exp <= 0) return AVI_EINVAL;
+    const int K = fbp->n_exp + NPF;
+    if (K > 160) return AVI_EINVAL;
+    const int KP = K <= 96 ? 96 : 160, Vp = (fbp->V + 15) / 16 * 16;
+    const long long total = 3LL * Vp * KP;
+    hipLaunchKernelGGL(flame_pack_basis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *fbp, Vp, KP, hi, lo);
     return avi_launch_status();
 }

@@ -12,7 +12,7 @@ from .. import lib as L
 
 
 class FLAME:
-    def __init__(self, buffers, n_shape=300, n_exp=50, device="cuda"):
+    def __init__(self, buffers, n_shape=300, n_exp=50, device="cuda", matrix_cores=True):
         """``buffers``: dict with the FLAME buffer names; ``shapedirs`` is (V, 3, n_shape + n_exp) as registered by
         the reference after its slicing (DecaFLAME.py:65-67)."""
         self.device = torch.device(device)
@@ -40,6 +40,14 @@ class FLAME:
         for k, t in self._keep.items():
             setattr(fb, k, t.data_ptr())
         fb.V, fb.n_shape, fb.n_exp = V, n_shape, n_exp
+        fb.basis_hi = fb.basis_lo = None
+        if matrix_cores and n_exp + 36 <= 160:
+            # split bf16 planes of the per-frame basis, [3][Vp][96|160]: the blend runs on the matrix cores
+            KP, Vp = (96 if n_exp + 36 <= 96 else 160), (V + 15) // 16 * 16
+            self._planes = torch.empty((2, 3 * Vp * KP), dtype=torch.int16, device=self.device)
+            L.check(L.load().avi_flame_pack_basis(C.byref(fb), self._planes[0].data_ptr(), self._planes[1].data_ptr(),
+                                                  L.stream_ptr()), "avi_flame_pack_basis")
+            fb.basis_hi, fb.basis_lo = self._planes[0].data_ptr(), self._planes[1].data_ptr()
         self.fb, self.V = fb, V
 
     def vertices(self, shape, exp, pose15):
@@ -50,8 +58,8 @@ class FLAME:
         shape, exp, pose15 = f(shape), f(exp), f(pose15)
         F, K = B * T, self.n_exp + 36
         vsh = torch.empty((B, self.V * 3), dtype=torch.float32, device=self.device)
-        coef = torch.empty(((F + 7) // 8 * 8 * K,), dtype=torch.float32, device=self.device)
-        xf = torch.empty((F, 60), dtype=torch.float32, device=self.device)
+        coef = torch.empty(((F + 7) // 8 * 8 * max(K, 160),), dtype=torch.float32, device=self.device)
+        xf = torch.empty((F * 60 + B * 16,), dtype=torch.float32, device=self.device)
         out = torch.empty((B, T, self.V, 3), dtype=torch.float32, device=self.device)
         L.check(L.load().avi_flame_vertices(C.byref(self.fb), shape.data_ptr(), exp.data_ptr(), pose15.data_ptr(), B, T,
                                             vsh.data_ptr(), coef.data_ptr(), xf.data_ptr(), out.data_ptr(),

@@ -36,7 +36,8 @@ class AviGemm(C.Structure):
 
 class AviFlameBasis(C.Structure):
     _fields_ = [(n, _vp) for n in ("v_template", "shape_basis", "frame_basis", "j_template", "j_shape", "j_exp",
-                                   "lbs_weights")] + [("V", _i), ("n_shape", _i), ("n_exp", _i)]
+                                   "lbs_weights")] + [("V", _i), ("n_shape", _i), ("n_exp", _i),
+                                                     ("basis_hi", _vp), ("basis_lo", _vp)]
 
 
 PRIOR_MAX_DEPTH = 8
@@ -80,6 +81,7 @@ SIGNATURES = {
     "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "avi_flame_vertices": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "avi_flame_pack_basis": [_vp, _vp, _vp, _vp],
     "avi_transpose_pack_split": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "avi_splitk_epilogue": [_vp, _i, _ll, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp],
     "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],

@@ -354,11 +354,19 @@ typedef struct AviFlameBasis {
     const float* j_exp;        /* [5*3][n_exp] */
     const float* lbs_weights;  /* [V][5] */
     int V, n_shape, n_exp;
+    /* optional (NULL = fp32 vector-pipe kernel): split bf16 planes of frame_basis written by avi_flame_pack_basis,
+     * [3][Vp][KP] each (Vp = V rounded up to 16; KP = 96 if n_exp + 36 <= 96, else 160): the blend runs on the
+     * matrix cores in 3-term bf16 */
+    const uint16_t* basis_hi;
+    const uint16_t* basis_lo;
 } AviFlameBasis;
 /* shape [B][n_shape] (one per clip), exp [B*T][n_exp], pose [B*T][15] = axis-angle of (global, neck, jaw, eye_l, eye_r)
- * -> verts [B*T][V][3].  Scratch: v_shaped B*V*3 floats, coef ceil(B*T/8)*8*(n_exp+36) floats, xf B*T*60 floats. */
+ * -> verts [B*T][V][3].  Scratch (16-byte aligned): v_shaped B*V*3 floats, coef ceil(B*T/8)*8*160 floats (covers both
+ * kernels), xf B*T*60 + B*16 floats (per-frame transforms, then the per-clip rest joints). */
 int avi_flame_vertices(const AviFlameBasis* fb, const float* shape, const float* exp, const float* pose, int B, int T,
                        float* v_shaped, float* coef, float* xf, float* verts, void* stream);
+/* Fill the optional basis planes of `fb` (see AviFlameBasis): hi / lo hold 3*Vp*KP uint16 each.  Once per model. */
+int avi_flame_pack_basis(const AviFlameBasis* fb, uint16_t* hi, uint16_t* lo, void* stream);
 
 #ifdef __cplusplus
 }
