@@ -52,6 +52,46 @@ __global__ void transpose_pack_kernel(const float* __restrict__ in, int R, int C
     }
 }
 
+// Several transposes in one launch: blockIdx.x runs over the 32x32 blocks of all jobs (first_block = prefix sum).
+struct TransposePack { AviTransposeJob j[4]; };
+__device__ __forceinline__ void transpose_job_block(const AviTransposeJob& jb, int local) {
+    __shared__ float tile[32][33];
+    const int Cp = jb.hi ? jb.C_pad : jb.C;
+    const int nbx = (Cp + 31) / 32;
+    const int bx = (local % nbx) * 32, by = (local / nbx) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < jb.R && c < jb.C) ? jb.in[(long long)r * jb.C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = bx + j, r = by + tx;
+        if (r >= jb.R) continue;
+        const float x = tile[tx][j];
+        if (jb.out && c < jb.C) jb.out[(long long)c * jb.R + r] = x;
+        if (jb.hi && c < jb.C_pad) {
+            const __bf16 h = (__bf16)x;
+            jb.hi[(long long)c * jb.R + r] = __builtin_bit_cast(uint16_t, h);
+            jb.lo[(long long)c * jb.R + r] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void transpose_jobs_kernel(const TransposePack p, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= p.j[j + 1].first_block) ++j;
+    transpose_job_block(p.j[j], blockIdx.x - p.j[j].first_block);
+}
+__global__ __launch_bounds__(256) void transpose_table_kernel(const AviTransposeJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;            // last job whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AviTransposeJob jb = jobs[lo];
+    transpose_job_block(jb, blockIdx.x - jb.first_block);
+}
+
 // block = 16 columns x 16 row groups: the rows of a column are walked by 16 threads and met in LDS in a fixed order
 // (one thread per column walking all rows serially took 15-20 us per call for 64..256 rows: pure load latency)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int Cc,
@@ -646,6 +686,31 @@ extern "C" int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pa
     if (!in || !hi || !lo || R <= 0 || Cc <= 0 || C_pad < Cc) return AVI_EINVAL;
     hipLaunchKernelGGL(transpose_pack_kernel, dim3((C_pad + 31) / 32, (R + 31) / 32), dim3(256), 0, S_(stream), in, R,
                        Cc, C_pad, hi, lo);
+    return avi_launch_status();
+}
+
+static int transpose_job_blocks(const AviTransposeJob& jb) {
+    const int Cp = jb.hi ? jb.C_pad : jb.C;
+    return ((Cp + 31) / 32) * ((jb.R + 31) / 32);
+}
+extern "C" int avi_transpose_jobs(const AviTransposeJob* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 1 || njobs > 4) return AVI_EINVAL;
+    TransposePack p{};
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const AviTransposeJob& jb = jobs[i];
+        if (!jb.in || (!jb.out && !jb.hi) || (jb.hi && !jb.lo) || jb.R <= 0 || jb.C <= 0 || (jb.hi && jb.C_pad < jb.C))
+            return AVI_EINVAL;
+        p.j[i] = jb;
+        p.j[i].first_block = total;
+        total += transpose_job_blocks(jb);
+    }
+    hipLaunchKernelGGL(transpose_jobs_kernel, dim3(total), dim3(256), 0, S_(stream), p, njobs);
+    return avi_launch_status();
+}
+extern "C" int avi_transpose_table(const AviTransposeJob* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || njobs < 1 || total_blocks < 1) return AVI_EINVAL;
+    hipLaunchKernelGGL(transpose_table_kernel, dim3(total_blocks), dim3(256), 0, S_(stream), jobs_dev, njobs);
     return avi_launch_status();
 }
 

@@ -106,12 +106,14 @@ class _Lin:
             raise ValueError("training batch rows must be a multiple of 64")
         dev = dy.device
         dyT = torch.empty((self.N, M), dtype=torch.float32, device=dev)
-        L.check(so.avi_transpose(dy.data_ptr(), M, self.N, dyT.data_ptr(), L.stream_ptr()), "transpose")
         Kp = 64 if self.K <= 64 else (self.K + 127) // 128 * 128
         xhi = torch.empty((Kp, M), dtype=torch.int16, device=dev)      # x^T as [K][M] hi/lo: the "weight" operand of
         xlo = torch.empty_like(xhi)                                    # the dW GEMM, transposed and split in one pass
-        L.check(so.avi_transpose_pack_split(x.data_ptr(), M, self.K, Kp, xhi.data_ptr(), xlo.data_ptr(), L.stream_ptr()),
-                "avi_transpose_pack_split")
+        jobs = (L.AviTransposeJob * 2)()                               # dY^T (fp32) and x^T (planes) in ONE launch
+        jobs[0].in_, jobs[0].out, jobs[0].R, jobs[0].C = dy.data_ptr(), dyT.data_ptr(), M, self.N
+        jobs[1].in_, jobs[1].hi, jobs[1].lo = x.data_ptr(), xhi.data_ptr(), xlo.data_ptr()
+        jobs[1].R, jobs[1].C, jobs[1].C_pad = M, self.K, Kp
+        L.check(so.avi_transpose_jobs(jobs, 2, L.stream_ptr()), "avi_transpose_jobs")
         ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xhi.data_ptr(), Wlo=xlo.data_ptr(),
                      C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
         if self.b:
@@ -249,6 +251,7 @@ class PriorTrainer:
         self.rel_index = dv(torch.clamp(q - k, min=0))                        # (3,4) bucket of each (i,j)
         self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
         self._works = []
+        self._ttable = None
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
@@ -271,8 +274,20 @@ class PriorTrainer:
 
     # ------------------------------------------------------------------ helpers
     def refresh(self):
-        for lin in self.lins:
-            lin.refresh_transposed()
+        """Transposed split planes of every weight that needs a dX GEMM, rebuilt after each optimizer step: one
+        launch over a device table of jobs (built once: parameter and plane addresses never change)."""
+        if self._ttable is None:
+            lins = [l for l in self.lins if l.need_dx]
+            jobs = (L.AviTransposeJob * len(lins))()
+            total = 0
+            for jb, l in zip(jobs, lins):
+                jb.in_, jb.hi, jb.lo = l.s.ptr(l.w), l.hiT.data_ptr(), l.loT.data_ptr()
+                jb.R, jb.C, jb.C_pad, jb.first_block = l.N, l.K, l.Kp, total
+                total += jb.blocks()
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+            self._ttable = (raw, len(lins), total)
+        raw, n, total = self._ttable
+        L.check(L.load().avi_transpose_table(raw.data_ptr(), n, total, L.stream_ptr()), "avi_transpose_table")
 
     def reload_planes(self):
         """Rebuild every derived copy of the parameters (bf16 hi/lo planes, transposed planes) after the flat fp32

@@ -40,6 +40,15 @@ class AviFlameBasis(C.Structure):
                                                      ("basis_hi", _vp), ("basis_lo", _vp)]
 
 
+class AviTransposeJob(C.Structure):
+    _fields_ = [("in_", _vp), ("out", _vp), ("hi", _vp), ("lo", _vp), ("R", _i), ("C", _i), ("C_pad", _i),
+                ("first_block", _i)]
+
+    def blocks(self):
+        cp = self.C_pad if self.hi else self.C
+        return ((cp + 31) // 32) * ((self.R + 31) // 32)
+
+
 PRIOR_MAX_DEPTH = 8
 
 
@@ -105,6 +114,8 @@ SIGNATURES = {
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_transpose": [_vp, _i, _i, _vp, _vp],
+    "avi_transpose_jobs": [_vp, _i, _vp],
+    "avi_transpose_table": [_vp, _i, _i, _vp],
     "avi_colsum": [_vp, _i, _i, _vp, _i, _vp],
     "avi_act_fwd": [_vp, _ll, _i, _vp, _vp],
     "avi_act_bwd": [_vp, _vp, _ll, _i, _vp, _vp],

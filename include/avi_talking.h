@@ -295,10 +295,26 @@ int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const
 int avi_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mask,
                       int rows, int C, float eps, int act, int stable, const float* dx_add, float* dx, float* dgamma,
                       float* dbeta, int accumulate, float* stats, void* stream);   /* dx = dLN/dx + dx_add (or NULL) */
-int avi_transpose(const float* in, int R, int C, float* out, void* stream);                 /* hi/lo [C_pad][R] = bf16 hi/lo split of in^T (in is [R][Cc] fp32; rows Cc..C_pad-1 are zero): the transposed
+/* [R][C] -> [C][R] */
+int avi_transpose(const float* in, int R, int C, float* out, void* stream);
+/* hi/lo [C_pad][R] = bf16 hi/lo split of in^T (in is [R][Cc] fp32; rows Cc..C_pad-1 are zero): the transposed
  * "weight" operand of avi_gemm for dW = dY^T X and dX = dY W in one pass. */
 int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pad, uint16_t* hi, uint16_t* lo, void* stream);
-/* [R][C] -> [C][R] */
+/* Several transposes in ONE launch (the training step is a chain of ~400 short launches: every launch saved is ~5 us).
+ * A job writes out (fp32 [C][R]) and/or hi/lo (split planes [C_pad][R], rows >= C zero); NULL outputs are skipped. */
+typedef struct AviTransposeJob {
+    const float* in;   /* [R][C] fp32 */
+    float* out;        /* [C][R] fp32 or NULL */
+    uint16_t* hi;      /* [C_pad][R] or NULL */
+    uint16_t* lo;
+    int R, C, C_pad;   /* C_pad >= C; ignored (taken as C) when hi is NULL */
+    int first_block;   /* device tables only: index of the job's first 32x32 block (prefix sum over the jobs) */
+} AviTransposeJob;
+/* jobs: HOST array of 1..4 jobs, passed to the kernel by value (dY^T and X^T of one backward GEMM pair) */
+int avi_transpose_jobs(const AviTransposeJob* jobs, int njobs, void* stream);
+/* jobs_dev: DEVICE table with first_block filled in, total_blocks = sum of the jobs' blocks (the per-step refresh of
+ * every transposed weight plane of the trainer: the table is built once) */
+int avi_transpose_table(const AviTransposeJob* jobs_dev, int njobs, int total_blocks, void* stream);
 int avi_colsum(const float* in, int R, int C, float* out, int accumulate, void* stream);     /* out[c] = sum_r */
 int avi_act_fwd(const float* x, long long n, int act, float* y, void* stream);
 int avi_act_bwd(const float* x_pre, const float* dy, long long n, int act, float* dx, void* stream);
