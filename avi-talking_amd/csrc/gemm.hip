@@ -212,187 +212,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// v2: same tile (128 x 128, 4 waves), K step 32, TWO LDS buffers and ONE barrier per step.  The register-staged tile
-// k+1 is converted and written into the idle buffer, and the global loads of tile k+2 are issued, BEFORE the MFMAs of
-// tile k, so LDS writes and HBM/L2 latency run under the matrix pipe of the same wave instead of in a separate
-// store phase between two barriers.  LDS rows are 128 B = [32 bf16 hi | 32 bf16 lo] with the (row&7) XOR swizzle
-// (conflict-free for the hi chunk g and the lo chunk 4+g of ds_read_b128).
-template <int NS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const AviGemm g, const int tilesM, const int tilesN) {
-    constexpr int BN = 128, BK2 = 32, TILE = 128 * 128;   // bytes per operand tile (128 rows x 128 B)
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = tilesM * tilesN;
-    int t = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = t / tilesN, tn = t - tm * tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-    const int zo = z / g.z_inner, zi = z - zo * g.z_inner;
-    const float* __restrict__ A = g.A + zo * g.sAo + zi * g.sAi;
-    const uint16_t* __restrict__ Whi = g.Whi + zo * g.sWo + zi * g.sWi;
-    const uint16_t* __restrict__ Wlo = (NS == 2) ? g.Wlo + zo * g.sWo + zi * g.sWi : nullptr;
-
-    // staging: thread -> (row r = tid/2, half hf = tid&1): 16 consecutive k of that row
-    const int r = tid >> 1, hf = tid & 1;
-    int mrow = m0 + r;
-    mrow = mrow < g.M ? mrow : g.M - 1;
-    const float* ap = A + (long long)mrow * g.lda + hf * 16;
-    const uint16_t* whp = Whi + (long long)(n0 + r) * (g.ldw ? g.ldw : g.K) + hf * 16;
-    const uint16_t* wlp = (NS == 2) ? Wlo + (long long)(n0 + r) * (g.ldw ? g.ldw : g.K) + hf * 16 : nullptr;
-    const int sw = r & 7;
-    const int o_h0 = r * 128 + (((2 * hf) ^ sw) << 4), o_h1 = r * 128 + (((2 * hf + 1) ^ sw) << 4);
-    const int o_l0 = r * 128 + (((4 + 2 * hf) ^ sw) << 4), o_l1 = r * 128 + (((5 + 2 * hf) ^ sw) << 4);
-
-    f32x4 ra[4];
-    u32x4 rwh[2], rwl[2];
-    auto load_tile = [&](const int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * i);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            rwh[i] = *reinterpret_cast<const u32x4*>(whp + k0 + 8 * i);
-            if (NS == 2) rwl[i] = *reinterpret_cast<const u32x4*>(wlp + k0 + 8 * i);
-        }
-    };
-    auto store_tile = [&](char* sa, char* sw_) __attribute__((always_inline)) {
-        bf16x8 h0, h1, l0, l1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x0 = ra[j >> 2][j & 3], x1 = ra[2 + (j >> 2)][j & 3];
-            h0[j] = (__bf16)x0;
-            h1[j] = (__bf16)x1;
-            if (NS == 2) {
-                l0[j] = (__bf16)(x0 - (float)h0[j]);
-                l1[j] = (__bf16)(x1 - (float)h1[j]);
-            }
-        }
-        *reinterpret_cast<bf16x8*>(sa + o_h0) = h0;
-        *reinterpret_cast<bf16x8*>(sa + o_h1) = h1;
-        *reinterpret_cast<u32x4*>(sw_ + o_h0) = rwh[0];
-        *reinterpret_cast<u32x4*>(sw_ + o_h1) = rwh[1];
-        if (NS == 2) {
-            *reinterpret_cast<bf16x8*>(sa + o_l0) = l0;
-            *reinterpret_cast<bf16x8*>(sa + o_l1) = l1;
-            *reinterpret_cast<u32x4*>(sw_ + o_l0) = rwl[0];
-            *reinterpret_cast<u32x4*>(sw_ + o_l1) = rwl[1];
-        }
-    };
-
-    constexpr int MT = 4, NT = 4;
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fq = lane >> 4;
-    // fragment offsets inside a tile (independent of the buffer)
-    int xo_h[MT], wo_h[NT];
-#pragma unroll
-    for (int b = 0; b < MT; ++b) {
-        const int row = wm * 64 + b * 16 + fr;
-        xo_h[b] = row * 128 + ((fq ^ (row & 7)) << 4);
-    }
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        const int row = wn * 64 + a * 16 + fr;
-        wo_h[a] = row * 128 + ((fq ^ (row & 7)) << 4);
-    }
-    // the lo chunk 4+fq of a row sits at (chunk ^ 4) of the hi chunk: XOR bit 6 of the byte offset
-    const int nk = g.K / BK2;
-    load_tile(0);
-    store_tile(smem, smem + TILE);
-    if (nk > 1) load_tile(BK2);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sa = smem + (kt & 1) * 2 * TILE;
-        const char* sw_ = sa + TILE;
-        bf16x8 xh[MT], xl[MT], wh[NT], wl[NT];
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            xh[b] = *reinterpret_cast<const bf16x8*>(sa + xo_h[b]);
-            if (NS == 2) xl[b] = *reinterpret_cast<const bf16x8*>(sa + (xo_h[b] ^ 64));
-        }
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            wh[a] = *reinterpret_cast<const bf16x8*>(sw_ + wo_h[a]);
-            if (NS == 2) wl[a] = *reinterpret_cast<const bf16x8*>(sw_ + (wo_h[a] ^ 64));
-        }
-        if (kt + 1 < nk) {
-            char* na = smem + ((kt + 1) & 1) * 2 * TILE;
-            store_tile(na, na + TILE);                    // tile kt+1: loaded one step ago
-            if (kt + 2 < nk) load_tile((kt + 2) * BK2);   // lands during this step's and the next step's MFMAs
-        }
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                if (NS == 2) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[a], xh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xl[b], acc[a][b], 0, 0, 0);
-                }
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xh[b], acc[a][b], 0, 0, 0);
-            }
-        __syncthreads();
-    }
-
-    float* __restrict__ C = g.C + zo * g.sCo + zi * g.sCi;
-    const float* __restrict__ bias = g.bias ? g.bias + zo * g.sBo + zi * g.sBi : nullptr;
-    const float* __restrict__ R = g.R ? g.R + zo * g.sRo + zi * g.sRi : nullptr;
-    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
-                        (!R || (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        const int n = n0 + wn * 64 + a * 16 + fq * 4;
-        if (n >= g.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < g.N) {
-                if (bias) bv[j] = bias[n + j];
-                if (g.scale) { sc[j] = g.scale[n + j]; sh[j] = g.shift[n + j]; }
-            }
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            const int m = m0 + wm * 64 + b * 16 + fr;
-            if (m >= g.M) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = avi_act(acc[a][b][j] + bv[j], g.act) * sc[j] + sh[j];
-            float* cp = C + (long long)m * g.ldc + n;
-            if (vec_ok && n + 3 < g.N) {
-                if (R) {
-                    const float4 rv = *reinterpret_cast<const float4*>(R + (long long)m * g.ldr + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < g.N) cp[j] = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
-            }
-        }
-    }
-}
-
-template <int NS>
-int launch_gemm_v2(const AviGemm& g, hipStream_t s) {
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + 127) / 128;
-    constexpr int smem = 4 * 128 * 128;   // 2 buffers x (A + W) x 16 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v2<NS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel_v2<NS>), dim3(tilesM * tilesN, g.batch), dim3(256), smem, s, g, tilesM, tilesN);
-    return avi_launch_status();
-}
 
 template <int BN, int NS>
 int launch_gemm(const AviGemm& g, hipStream_t s) {
@@ -445,7 +264,7 @@ static double tile_score(const AviGemm& g, int bm, int bn, double eff) {
     return eff * (double)g.M * g.N * g.batch / ((double)rounds * cus * bm * bn);
 }
 
-static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL=3: double-buffered v2 kernel for fp32 A; 2/4/5: see below
+static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL = 2 / 4 / 5 / 6: A/B switches of the plane-operand dispatch below
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("AVI_GEMM_KERNEL");
@@ -496,9 +315,6 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
         return avi_gemm_dma_launch(g, s);
     }
     const bool narrow = g.N <= 64;
-    if (!narrow && (g.prec & 0x300) == 0) {
-        if (gemm_kernel_choice() == 3) return prec == AVI_PREC_BF16X3 ? launch_gemm_v2<2>(g, s) : launch_gemm_v2<1>(g, s);
-    }
     if (prec == AVI_PREC_BF16X3) return narrow ? launch_gemm<64, 2>(g, s) : launch_gemm<128, 2>(g, s);
     return narrow ? launch_gemm<64, 1>(g, s) : launch_gemm<128, 1>(g, s);
 }

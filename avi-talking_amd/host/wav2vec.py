@@ -43,9 +43,6 @@ class Wav2Vec2Model:
         # (AVI_W2V_TF_PLANES=0: fp32 activations + gemm.hip's 128x128 tiles).
         self.use_planes = os.environ.get("AVI_W2V_PLANES", "1") == "1"
         self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "1") == "1"
-        # optional callable run on the launch stream between conv layer 0 and the chip-filling conv GEMMs (the
-        # sampling pipeline makes the main stream wait there for the aligner network of the prior branch)
-        self.before_conv_stack = None
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -100,14 +97,10 @@ class Wav2Vec2Model:
         its epilogue and the LDS-DMA GEMM consumes the planes without any conversion in its loop."""
         if not self.use_planes:
             h = ops.conv0_gn_gelu(input_values, self.w0, self.gn_g, self.gn_b)
-            if self.before_conv_stack is not None:
-                self.before_conv_stack()
             for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
                 h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
             return h
         h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b)
-        if self.before_conv_stack is not None:
-            self.before_conv_stack()
         n = len(self.convs)
         for i, (pw, k, s) in enumerate(zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:])):
             h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec, out_planes=i + 1 < n)
