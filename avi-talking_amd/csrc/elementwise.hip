@@ -285,8 +285,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
         const int idx = tid + 256 * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < nv) {
-            for (int z = 0; z < nparts; ++z) {
-                const float4 p = reinterpret_cast<const float4*>(parts + z * part_stride + (long long)row * C)[idx];
+            // eight partial sums in flight, added in z order (one dependent load per z cost 24 us for 16 slices)
+            const float* pp = parts + (long long)row * C;
+            int z = 0;
+            for (; z + 8 <= nparts; z += 8) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = reinterpret_cast<const float4*>(pp + (z + u) * part_stride)[idx];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[i].x += p[u].x; v[i].y += p[u].y; v[i].z += p[u].z; v[i].w += p[u].w; }
+            }
+            for (; z < nparts; ++z) {
+                const float4 p = reinterpret_cast<const float4*>(pp + z * part_stride)[idx];
                 v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
             }
             if (bias) {

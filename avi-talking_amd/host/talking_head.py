@@ -159,7 +159,10 @@ class EmoteHead:
         d = ops.linear(d, self.dec, prec=P)
         T_pad = int(math.ceil(T / LATENT_FRAME) * LATENT_FRAME)
         dp = ops.pad_repeat(d, 1, 0, T_pad - T, 0)
-        z = ops.linear(dp.view(B, T_pad // LATENT_FRAME, LATENT_FRAME * 256), self.squash, prec=P)
+        # (B*T/8) x 2048 -> 256: sixteen 128-row tiles walking 32 K tiles each are pure latency (72 us); K slices as
+        # one batched launch + the partial-sum epilogue take a third of that
+        z = ops.linear_ln_skinny(dp.view(B, T_pad // LATENT_FRAME, LATENT_FRAME * 256), self.squash, do_ln=False,
+                                 prec=P)
         seq = self.flint_decoder(z)[:, :T]
         return {"seq_encoder_output": h, "latent": z,
                 "predicted_exp": seq[..., :N_EXP], "predicted_jaw": seq[..., N_EXP:N_EXP + N_JAW]}

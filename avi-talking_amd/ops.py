@@ -173,7 +173,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, act=ACT_NONE, residual=None):
 
 def linear_ln_skinny(x, pw, gamma=None, beta=None, eps=1e-5, do_ln=True, act=ACT_NONE, residual=None,
                      prec=PREC_BF16X3, kslice=256):
-    """out = act(LN(x @ W^T + b)) + residual for a handful of rows (M <= 32: the aligner MLP at batch-size rows).
+    """out = act(LN(x @ W^T + b)) + residual for few row tiles and a long K (the aligner MLP at batch-size rows, the
+    EMOTE squasher at B*T/8 rows).
 
     A 128-row GEMM tile would be three quarters padding and a 4096-long K loop on 32 workgroups is pure latency,
     so K is cut into slices that run as one batched launch (hundreds of workgroups stream the weight matrix at
