@@ -15,7 +15,7 @@
 // [frames x 96] . [96 x V*3] product in 3-term split bf16 on the matrix cores, one wave per 16 vertices x all frames
 // of one clip with the basis fragments resident in registers; the skinning runs on the accumulators (a lane holds
 // x, y, z of 4 consecutive vertices of one frame) and the result leaves as 48 contiguous bytes per lane.
-// flame_vertices_kernel (fallback for bases wider than 160 vectors or without planes): all fp32 on the vector pipe,
+// flame_vertices_kernel (no planes given; up to 106 basis vectors, all held in LDS): all fp32 on the vector pipe,
 // block = 128 vertices x all frames of one clip; 512 threads = 128 vertices x 4 frame
 // subgroups, 8 frames in flight per thread (24 accumulators); per-frame coefficients are wave-uniform (scalar loads)
 // and stored frame-group-major [f/8][k][8] by flame_frame_kernel so that one 32-byte scalar load feeds 8 frames.

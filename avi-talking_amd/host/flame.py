@@ -41,7 +41,12 @@ class FLAME:
             setattr(fb, k, t.data_ptr())
         fb.V, fb.n_shape, fb.n_exp = V, n_shape, n_exp
         fb.basis_hi = fb.basis_lo = None
-        if matrix_cores and n_exp + 36 <= 160:
+        # matrix-core kernel: up to 160 per-frame basis vectors (n_exp <= 124; FLAME has 100, the reference uses 50);
+        # the fp32 vector-pipe kernel keeps all of them in LDS: up to 106 (n_exp <= 70)
+        if n_exp + 36 > (160 if matrix_cores else 106):
+            raise ValueError(f"n_exp = {n_exp}: more per-frame basis vectors than the "
+                             f"{'matrix-core' if matrix_cores else 'vector-pipe'} kernel holds")
+        if matrix_cores:
             # split bf16 planes of the per-frame basis, [3][Vp][96|160]: the blend runs on the matrix cores
             KP, Vp = (96 if n_exp + 36 <= 96 else 160), (V + 15) // 16 * 16
             self._planes = torch.empty((2, 3 * Vp * KP), dtype=torch.int16, device=self.device)

@@ -70,3 +70,36 @@ def test_flame_from_coefficients_and_full_size_properties(gpu, basis):
     assert torch.isfinite(full).all()
     sub = fl.from_coefficients(shape[7:9], exp[7:9, 100:103], jaw[7:9, 100:103])
     assert torch.equal(sub, full[7:9, 100:103])                                   # frames independent, bit-exact
+
+
+@pytest.mark.parametrize("n_exp,V,matrix_cores", [(50, 5023, False), (100, 333, True), (70, 333, False),
+                                                  (124, 130, True), (20, 47, True)])
+def test_flame_kernel_variants_match_oracle(gpu, n_exp, V, matrix_cores):
+    """The fp32 vector-pipe kernel, the 160-wide matrix-core instantiation (n_exp = 100 -> 136 basis vectors, and its
+    limit 124), the vector-pipe limit (70) and tiny ragged vertex counts."""
+    from avi_talking_amd.host.flame import FLAME
+    from avi_talking_amd.weights import make_flame_basis
+    from oracle import flame as OF
+    basis = make_flame_basis(9, n_vertices=V, n_exp=n_exp)
+    B, T = 3, 21
+    g = torch.Generator().manual_seed(n_exp + V)
+    shape = torch.randn(B, 300, generator=g)
+    exp = torch.randn(B, T, n_exp, generator=g) * 0.8
+    pose = torch.randn(B, T, 15, generator=g) * 0.12
+    fl = FLAME(basis, n_exp=n_exp, device=gpu, matrix_cores=matrix_cores)
+    assert (fl.fb.basis_hi is not None) == matrix_cores
+    out = fl.vertices(shape.to(gpu), exp.to(gpu), pose.to(gpu)).cpu()
+    assert out.shape == (B, T, V, 3)
+    for b, t in [(0, 0), (B - 1, T - 1), (1, 16), (2, 15)]:
+        betas = torch.cat([shape[b], exp[b, t]])[None]
+        ref = OF.lbs(betas, pose[b, t][None], basis)[0][0]
+        assert (out[b, t] - ref).abs().max().item() < 2e-6, (b, t)
+
+
+def test_flame_rejects_bases_wider_than_the_kernels(gpu):
+    from avi_talking_amd.host.flame import FLAME
+    from avi_talking_amd.weights import make_flame_basis
+    with pytest.raises(ValueError):
+        FLAME(make_flame_basis(9, n_vertices=64, n_exp=125), n_exp=125, device=gpu)
+    with pytest.raises(ValueError):
+        FLAME(make_flame_basis(9, n_vertices=64, n_exp=71), n_exp=71, device=gpu, matrix_cores=False)

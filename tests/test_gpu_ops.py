@@ -255,3 +255,47 @@ def test_planes_gemm_tile_shapes(gpu, M, N, K, budget):
     err = (out - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), err
     assert (outp.float().cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, (K / 64) ** 0.5) + 1e-4
+
+
+def test_transpose_jobs_and_table(gpu):
+    """avi_transpose_jobs (jobs by value) and avi_transpose_table (device table): fp32 and split-plane outputs, ragged
+    shapes (rows / columns not multiples of the 32x32 block), padded plane rows zero."""
+    import ctypes as C
+    from avi_talking_amd import lib as L
+    so = L.load()
+    g = torch.Generator().manual_seed(3)
+    specs = [(70, 45, 64, True, True), (192, 640, 640, True, False), (33, 130, 256, False, True), (1, 7, 64, False, True)]
+    jobs = (L.AviTransposeJob * len(specs))()
+    keep, total = [], 0
+    for jb, (R, Cc, Cp, want_f32, want_planes) in zip(jobs, specs):
+        x = torch.randn(R, Cc, generator=g).to(gpu)
+        out = torch.full((Cc, R), 7.0, device=gpu) if want_f32 else None
+        hi = torch.full((Cp, R), 0x1234, dtype=torch.int16, device=gpu) if want_planes else None
+        lo = torch.full((Cp, R), 0x1234, dtype=torch.int16, device=gpu) if want_planes else None
+        jb.in_, jb.out, jb.hi, jb.lo = x.data_ptr(), L.ptr(out) or None, L.ptr(hi) or None, L.ptr(lo) or None
+        jb.R, jb.C, jb.C_pad, jb.first_block = R, Cc, Cp, total
+        total += jb.blocks()
+        keep.append((x, out, hi, lo, Cc))
+
+    def check():
+        for x, out, hi, lo, Cc in keep:
+            if out is not None:
+                assert torch.equal(out, x.t())
+            if hi is not None:
+                v = hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float()
+                assert (v[:Cc] - x.t()).abs().max().item() < 2e-5 * x.abs().max().item()
+                assert torch.equal(hi[:Cc].view(torch.bfloat16), x.t().contiguous().to(torch.bfloat16))
+                assert not v[Cc:].any()
+
+    L.check(so.avi_transpose_jobs(jobs, len(specs), L.stream_ptr()), "avi_transpose_jobs")
+    torch.cuda.synchronize()
+    check()
+    for _, out, hi, lo, _ in keep:          # again through a device table
+        for t in (out, hi, lo):
+            if t is not None:
+                t.fill_(1)
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(gpu)
+    L.check(so.avi_transpose_table(table.data_ptr(), len(specs), total, L.stream_ptr()), "avi_transpose_table")
+    torch.cuda.synchronize()
+    check()
+    assert so.avi_transpose_jobs(jobs, 5, L.stream_ptr()) != 0      # at most four jobs by value
