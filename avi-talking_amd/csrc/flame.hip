@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                                                                    const uint16_t* __restrict__ clo,
                                                                    const float* __restrict__ xf, int T, int Vp,
                                                                    float* __restrict__ verts) {
-    constexpr int KP = KS * 32;
+    constexpr int KP = KS * 32, SLAB_ROW = 52;   // 48 floats per frame row + 4 of padding (bank spread of the writes)
+    __shared__ __attribute__((aligned(16))) float slabs[4 * 16 * SLAB_ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int vt = blockIdx.x * 4 + wave, b = blockIdx.y;
@@ -336,17 +337,29 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                 o[j * 3 + r] = t[0] * px[j] + t[1] * py[j] + t[2] * pz[j] + t[3];
             }
         }
-        if (f < fend) {
-            float* op = verts + ((long long)f * fb.V + vb) * 3;
-            if (vb + 3 < fb.V) {
+        if (vt * 16 + 16 <= fb.V) {
+            // Full vertex tile: the wave's 16 frames x 192 B go through a private LDS slab so that every store
+            // instruction writes whole 192-byte runs (12 consecutive lanes = one frame's 16 vertices) instead of 16-byte
+            // pieces 48 bytes apart (which held the store phase to 3.4 TB/s).
+            float* slab = slabs + wave * (16 * SLAB_ROW);
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    *reinterpret_cast<f32x4u*>(op + 4 * i) = (f32x4u){o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
-            } else {
+            for (int i = 0; i < 3; ++i)
+                *reinterpret_cast<f32x4*>(slab + fr * SLAB_ROW + fq * 12 + 4 * i) =
+                    (f32x4){o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, other lanes' rows
 #pragma unroll
-                for (int i = 0; i < 12; ++i)
-                    if (vb + i / 3 < fb.V) op[i] = o[i];
+            for (int i = 0; i < 3; ++i) {
+                const int cidx = i * 64 + lane, fl = cidx / 12, piece = cidx - fl * 12;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(slab + fl * SLAB_ROW + piece * 4);
+                if (f0 + fl < fend)
+                    *reinterpret_cast<f32x4u*>(verts + ((long long)(f0 + fl) * fb.V + vt * 16) * 3 + piece * 4) = val;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next tile rewrites it
+        } else if (f < fend) {   // last, partial vertex tile
+            float* op = verts + ((long long)f * fb.V + vb) * 3;
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (vb + i / 3 < fb.V) op[i] = o[i];
         }
     }
 }
