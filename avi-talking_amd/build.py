@@ -12,6 +12,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libavi_talking_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# No packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Measured on MI355X: a kernel whose
+# waves execute them returns wrong values (one half of a register pair, across the lanes of a wave) while waves of a
+# matrix-core kernel launched from ANOTHER stream share its SIMDs; alone, serialised, or built without these
+# instructions the same kernel is bit-exact (scripts/diag_concurrency.py: 100 % of runs wrong -> 0 %).  The sampling
+# pipeline overlaps a second stream with the audio branch, so every translation unit is built without them; the cost
+# is below the run-to-run noise of the step (AVI_PACKED_FP32=1 restores them for the diagnostic).
+if os.environ.get("AVI_PACKED_FP32", "0") != "1":
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS += os.environ.get("AVI_DEFINES", "").split()      # e.g. -DAVI_PP_STAMPS for scripts/pp_stamps.py
 
 

@@ -11,6 +11,8 @@ reference runs batch 1), wav2vec2 runs once per utterance (the reference runs it
 train_diffusion_prior.py:696 vs :764), no host syncs (NaN sweeps, .item()) and no per-step Python in
 the DDPM loop; the prior is sampled on a second HIP stream concurrently with the audio encoder.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -44,15 +46,18 @@ class SamplingPipeline:
         T = N // 640
         cur = torch.cuda.current_stream(self.device)
         # 1. Aligner MLP on the launch stream, before anything else (0.25 ms: split-K launches that stream the 300 MB
-        #    of weights at HBM speed).  It must not run beside the audio branch: with kernels starting and finishing
-        #    on a second stream while conv layer 0 was writing its 2 GB output, rows at both ends of that output came
-        #    out wrong (1e-3 .. 1e0, eager and graph replay alike; serial runs and a single long-running kernel on the
-        #    second stream are bit-exact - scripts/diag_concurrency.py).  So the only work that overlaps the audio
-        #    branch is ONE launch: the 100-step sampler.
-        clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
+        #    of weights at HBM speed).  On the second stream its ten launches each queue behind resident GEMM
+        #    workgroups of the audio branch and the sampler starts late (+0.4 ms per step, measured);
+        #    AVI_ALIGNER_SIDE=1 selects that arrangement for tests/test_gpu_fullsize.py, which pins that overlapping
+        #    short matrix-core launches with conv layer 0 no longer corrupts it (build.py: no packed-FP32 instructions).
+        aligner_on_side = os.environ.get("AVI_ALIGNER_SIDE", "0") == "1"
+        if not aligner_on_side:
+            clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
         # 2. fork: the sampler (32 workgroups for ~12 ms) on the side stream, the audio encoder on this one
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
+            if aligner_on_side:
+                clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
             style = self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
                                              cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
                                              noise=noise)

@@ -1,8 +1,17 @@
-"""Minimal reproduction of the concurrency hazard that shaped SamplingPipeline.run (dev tool).
+"""Reproduction of the concurrency hazard behind build.py's "-packed-fp32-ops" (dev tool).
 
-conv layer 0 (moments -> finalize -> apply, one stream) next to a loop of small GEMM launches on a second stream:
-rows at both ends of conv0's 2 GB output come out wrong although its inputs (audio, GroupNorm scale/shift) are exact;
-the same work run serially, or next to ONE long-running kernel on the second stream, is bit-exact.
+conv layer 0 (moments -> finalize -> apply, one stream) next to a loop of small GEMM launches on a second stream.
+With a library built WITH packed-FP32 instructions (AVI_PACKED_FP32=1 python avi-talking_amd/build.py) rows of conv0's
+2 GB output come out wrong in every run - one half of a register pair (channel q = 0 or 2 of the 4 a lane computes),
+for runs of consecutive lanes - although its inputs (audio, GroupNorm scale/shift) are exact; the same work run
+serially is bit-exact.  What was ruled in and out (MI355X, ROCm 7.2):
+  * aggressor = the GEMM with its LDS fragment reads + MFMAs skipped (SIDE=gemm_nomfma), a fill kernel (SIDE=fill) or a
+    LayerNorm (SIDE=ln): clean; GEMM without its global loads (SIDE=gemm_noload): still wrong -> matrix-core waves
+    sharing the victim's SIMDs are required (the 100-step sampler holds its CUs exclusively and never did harm);
+  * all accumulators consumed before the aggressor's waves end (GM=128), 80 idle cycles before its epilogue: still wrong;
+  * victim without LDS staging, with non-temporal stores, second stream at normal priority (PRIO=0): still wrong;
+  * victim (elementwise.hip) compiled without v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: CLEAN, 12 of 12 runs.
+So the library is built without packed-FP32 instructions and this script prints zero differences.
   python scripts/diag_concurrency.py overlap | serial      (PRIO=0 for a normal-priority second stream)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,10 +39,18 @@ print('side stream priority', side.priority)
 def conv0():
     L.check(L.load().avi_conv0_gn_gelu(x.data_ptr(), B, N, am.w0.data_ptr(), am.gn_g.data_ptr(), am.gn_b.data_ptr(), 1e-5,
                                        y.data_ptr(), mom.data_ptr(), ss.data_ptr(), L.stream_ptr()), "conv0")
+SIDE = os.environ.get("SIDE", "gemm")     # aggressor on the second stream: gemm | gemm_nomfma | gemm_noload | fill | ln
+fill_buf = torch.empty(2 * 1024 * 1024, device=dev)
+ln_in = torch.randn(32, 4096, device=dev); ln_g = torch.ones(4096, device=dev); ln_b = torch.zeros(4096, device=dev)
 def gemms(n):
     for _ in range(n):
+        if SIDE == "fill":
+            fill_buf.fill_(1.0); continue
+        if SIDE == "ln":
+            ops.layernorm(ln_in, ln_g, ln_b); continue
         ops.gemm_raw(A=xin.data_ptr(), lda=4096, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=parts.data_ptr(), ldc=4096,
-                     M=int(os.environ.get("GM", "32")), N=4096, K=256, prec=3, batch=16, sA=(256, 0), sW=(256, 0), sC=(32 * 4096, 0), ldw=4096)
+                     M=int(os.environ.get("GM", "32")), N=4096, K=256,
+                     prec=3 | (0x200 if SIDE == "gemm_nomfma" else 0) | (0x100 if SIDE == "gemm_noload" else 0), batch=16, sA=(256, 0), sW=(256, 0), sC=(32 * 4096, 0), ldw=4096)
 conv0(); torch.cuda.synchronize()
 good = y.clone(); ss_good = ss.clone(); mom_good = mom.clone()
 ssr = ss.view(B, 2, 512)

@@ -5,8 +5,9 @@
   in a fixed order that does not depend on which rows share its GEMM tile, attention workgroup or split-K slice);
 * a sub-batch reproduces the rows of the full batch (the oracle pins those rows at small sizes elsewhere);
 * hipGraph replays equal the eager pass, run to run, and BOTH equal a fully serial pass (sampler and audio encoder on
-  one stream): the two-stream overlap must not change a single bit.  (An earlier arrangement, with the aligner's
-  dozen small launches next to conv layer 0, did: scripts/diag_concurrency.py.)
+  one stream): the two-stream overlap must not change a single bit.  This also holds with the aligner's dozen short
+  matrix-core launches next to conv layer 0 (AVI_ALIGNER_SIDE=1), the arrangement that corrupted rows of conv layer 0
+  while the library still contained packed-FP32 instructions (build.py, scripts/diag_concurrency.py).
 Per-clip audio normalisation is used so that clips do not interact through the batch statistics (the joint mode of
 AudioEncoders.py:170-178 couples them by design and is covered at small sizes by tests/test_gpu_emote.py)."""
 import pytest
@@ -53,6 +54,34 @@ def test_config1_batch_permutation_and_subbatch(gpu):
     # graph replays == eager == serial, several times
     pipe.capture(pcm, voxel, noise)
     for _ in range(4):
+        rep = pipe.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rep["predicted_exp"], exp) and torch.equal(rep["predicted_jaw"], jaw)
+
+
+def test_config1_aligner_overlapping_the_audio_branch(gpu, monkeypatch):
+    """The aligner's short matrix-core launches on the second stream, beside conv layer 0 and the conv GEMMs: eager
+    passes and graph replays must equal the serial pass bit for bit (they did not before packed-FP32 instructions
+    were removed from the build)."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu,
+                            joint_norm=False)
+    pcm, voxel, noise = (t.to(gpu) for t in _inputs(32, 99))
+    side, pipe.side = pipe.side, torch.cuda.current_stream(gpu)
+    try:
+        ser = pipe.run(pcm, voxel, noise)
+        exp, jaw = ser["predicted_exp"].clone(), ser["predicted_jaw"].clone()
+        torch.cuda.synchronize()
+    finally:
+        pipe.side = side
+    monkeypatch.setenv("AVI_ALIGNER_SIDE", "1")
+    for _ in range(3):
+        out = pipe.run(pcm, voxel, noise)
+        torch.cuda.synchronize()
+        assert torch.equal(out["predicted_exp"], exp) and torch.equal(out["predicted_jaw"], jaw)
+    pipe.capture(pcm, voxel, noise)
+    for _ in range(3):
         rep = pipe.replay()
         torch.cuda.synchronize()
         assert torch.equal(rep["predicted_exp"], exp) and torch.equal(rep["predicted_jaw"], jaw)
