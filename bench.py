@@ -136,7 +136,7 @@ def main():
                    "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
         "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-        "roofline": None, "cpu_baseline": None, "train": None, "flame": None,
+        "roofline": None, "cpu_baseline": None, "train": None, "flame": None, "clip_text": None,
     }
     printed = threading.Lock()
 
@@ -168,6 +168,11 @@ def main():
             line["flame"] = measure_flame(dev)
         except Exception as e:
             line["flame"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0 and not args.no_train:
+        try:
+            line["clip_text"] = measure_clip_text(dev)
+        except Exception as e:
+            line["clip_text"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_train:
         try:
             line["train"] = measure_train(wp, dev, world, rank, local_rank, dist, args)
@@ -208,6 +213,31 @@ def measure_flame(dev, reps=10):
             "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(B_CLIPS * T_FRAMES / dt, 1),
             "roofline": {"bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(nbytes / dt / 8e12, 4)}}
+
+
+def measure_clip_text(dev, reps=10):
+    """the frozen CLIP text tower (12 layers, 768 wide, 77 tokens) over one batch of 32 prompts,
+    random-init weights of that architecture, one hipGraph replay per batch; the best replay is reported."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.clip_text import FrozenCLIPEmbedder
+    m = FrozenCLIPEmbedder(W.make_clip_text_weights(5), device=dev)
+    ids = torch.randint(0, 49408, (B_CLIPS, 77), generator=torch.Generator().manual_seed(3))
+    m.capture(ids)
+    m.replay()
+    torch.cuda.synchronize(dev)
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        m.replay()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize(dev)
+    ms = min(a.elapsed_time(b) for a, b in evs)
+    flops = 2.0 * B_CLIPS * 77 * 12 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072)
+    return {"workload": "CLIP text tower, 32 prompts x 77 tokens (random-init weights), hipGraph replay",
+            "ms_per_batch": round(ms, 3), "prompts_per_s": round(B_CLIPS / ms * 1e3, 1),
+            "algorithmic_tflops": round(flops / ms / 1e9, 1)}
 
 
 def measure_train(wp, dev, world, rank, local_rank, dist, args):
