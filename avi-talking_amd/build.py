@@ -39,6 +39,11 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "avi_talking.h"))
+    # objects compiled with other flags (e.g. a diagnostic AVI_PACKED_FP32=1 / AVI_DEFINES build) are never reused
+    stamp = os.path.join(objdir, "flags.txt")
+    flags = " ".join([HIPCC] + FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
@@ -51,6 +56,8 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    with open(stamp, "w") as fh:
+        fh.write(flags)
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
