@@ -77,10 +77,30 @@ __device__ __forceinline__ void transpose_job_block(const AviTransposeJob& jb, i
         }
     }
 }
+// column-sum job: block = 16 columns x 16 row groups, partial sums met in LDS in a fixed order (as colsum_kernel)
+__device__ __forceinline__ void colsum_job_block(const AviTransposeJob& jb, int local) {
+    __shared__ float ps[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = local * 16 + tx;
+    float s = 0.f;
+    if (c < jb.C) {
+#pragma unroll 4
+        for (int r = ty; r < jb.R; r += 16) s += jb.in[(long long)r * jb.C + c];
+    }
+    ps[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < jb.C) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += ps[j][tx];
+        jb.colsum[c] = s;
+    }
+}
 __global__ __launch_bounds__(256) void transpose_jobs_kernel(const TransposePack p, int njobs) {
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= p.j[j + 1].first_block) ++j;
-    transpose_job_block(p.j[j], blockIdx.x - p.j[j].first_block);
+    if (p.j[j].colsum) colsum_job_block(p.j[j], blockIdx.x - p.j[j].first_block);   // uniform per block
+    else transpose_job_block(p.j[j], blockIdx.x - p.j[j].first_block);
 }
 __global__ __launch_bounds__(256) void transpose_table_kernel(const AviTransposeJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;            // last job whose first_block <= blockIdx.x
@@ -89,7 +109,8 @@ __global__ __launch_bounds__(256) void transpose_table_kernel(const AviTranspose
         if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const AviTransposeJob jb = jobs[lo];
-    transpose_job_block(jb, blockIdx.x - jb.first_block);
+    if (jb.colsum) colsum_job_block(jb, blockIdx.x - jb.first_block);
+    else transpose_job_block(jb, blockIdx.x - jb.first_block);
 }
 
 // block = 16 columns x 16 row groups: the rows of a column are walked by 16 threads and met in LDS in a fixed order
@@ -690,6 +711,7 @@ extern "C" int avi_transpose_pack_split(const float* in, int R, int Cc, int C_pa
 }
 
 static int transpose_job_blocks(const AviTransposeJob& jb) {
+    if (jb.colsum) return (jb.C + 15) / 16;
     const int Cp = jb.hi ? jb.C_pad : jb.C;
     return ((Cp + 31) / 32) * ((jb.R + 31) / 32);
 }
@@ -699,7 +721,8 @@ extern "C" int avi_transpose_jobs(const AviTransposeJob* jobs, int njobs, void* 
     int total = 0;
     for (int i = 0; i < njobs; ++i) {
         const AviTransposeJob& jb = jobs[i];
-        if (!jb.in || (!jb.out && !jb.hi) || (jb.hi && !jb.lo) || jb.R <= 0 || jb.C <= 0 || (jb.hi && jb.C_pad < jb.C))
+        if (!jb.in || jb.R <= 0 || jb.C <= 0) return AVI_EINVAL;
+        if (jb.colsum ? (jb.out || jb.hi) : ((!jb.out && !jb.hi) || (jb.hi && !jb.lo) || (jb.hi && jb.C_pad < jb.C)))
             return AVI_EINVAL;
         p.j[i] = jb;
         p.j[i].first_block = total;

@@ -109,15 +109,15 @@ class _Lin:
         Kp = 64 if self.K <= 64 else (self.K + 127) // 128 * 128
         xhi = torch.empty((Kp, M), dtype=torch.int16, device=dev)      # x^T as [K][M] hi/lo: the "weight" operand of
         xlo = torch.empty_like(xhi)                                    # the dW GEMM, transposed and split in one pass
-        jobs = (L.AviTransposeJob * 2)()                               # dY^T (fp32) and x^T (planes) in ONE launch
+        jobs = (L.AviTransposeJob * 3)()              # dY^T (fp32), x^T (planes) and the bias gradient in ONE launch
         jobs[0].in_, jobs[0].out, jobs[0].R, jobs[0].C = dy.data_ptr(), dyT.data_ptr(), M, self.N
         jobs[1].in_, jobs[1].hi, jobs[1].lo = x.data_ptr(), xhi.data_ptr(), xlo.data_ptr()
         jobs[1].R, jobs[1].C, jobs[1].C_pad = M, self.K, Kp
-        L.check(so.avi_transpose_jobs(jobs, 2, L.stream_ptr()), "avi_transpose_jobs")
+        if self.b:
+            jobs[2].in_, jobs[2].colsum, jobs[2].R, jobs[2].C = dy.data_ptr(), self.s.gptr(self.b), M, self.N
+        L.check(so.avi_transpose_jobs(jobs, 3 if self.b else 2, L.stream_ptr()), "avi_transpose_jobs")
         ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xhi.data_ptr(), Wlo=xlo.data_ptr(),
                      C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
-        if self.b:
-            L.check(so.avi_colsum(dy.data_ptr(), M, self.N, self.s.gptr(self.b), 0, L.stream_ptr()), "colsum")
         if not self.need_dx:
             return None
         if self._use_skinny(M, self.K, self.N):

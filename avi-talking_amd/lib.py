@@ -42,9 +42,11 @@ class AviFlameBasis(C.Structure):
 
 class AviTransposeJob(C.Structure):
     _fields_ = [("in_", _vp), ("out", _vp), ("hi", _vp), ("lo", _vp), ("R", _i), ("C", _i), ("C_pad", _i),
-                ("first_block", _i)]
+                ("first_block", _i), ("colsum", _vp)]
 
     def blocks(self):
+        if self.colsum:
+            return (self.C + 15) // 16
         cp = self.C_pad if self.hi else self.C
         return ((cp + 31) // 32) * ((self.R + 31) // 32)
 

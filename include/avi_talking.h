@@ -308,7 +308,9 @@ typedef struct AviTransposeJob {
     uint16_t* hi;      /* [C_pad][R] or NULL */
     uint16_t* lo;
     int R, C, C_pad;   /* C_pad >= C; ignored (taken as C) when hi is NULL */
-    int first_block;   /* device tables only: index of the job's first 32x32 block (prefix sum over the jobs) */
+    int first_block;   /* device tables only: index of the job's first block (prefix sum over the jobs) */
+    float* colsum;     /* non-NULL (with out = hi = NULL): the job is colsum[c] = sum_r in[r][c] instead (a bias
+                        * gradient riding in the same launch), ceil(C/16) blocks */
 } AviTransposeJob;
 /* jobs: HOST array of 1..4 jobs, passed to the kernel by value (dY^T and X^T of one backward GEMM pair) */
 int avi_transpose_jobs(const AviTransposeJob* jobs, int njobs, void* stream);

@@ -299,3 +299,13 @@ def test_transpose_jobs_and_table(gpu):
     torch.cuda.synchronize()
     check()
     assert so.avi_transpose_jobs(jobs, 5, L.stream_ptr()) != 0      # at most four jobs by value
+    # a column-sum job riding in the same launch (the bias gradient of a backward GEMM pair)
+    x = torch.randn(192, 45, generator=g).to(gpu)
+    cs = torch.full((45,), 3.0, device=gpu)
+    xt = torch.empty((45, 192), device=gpu)
+    two = (L.AviTransposeJob * 2)()
+    two[0].in_, two[0].out, two[0].R, two[0].C = x.data_ptr(), xt.data_ptr(), 192, 45
+    two[1].in_, two[1].colsum, two[1].R, two[1].C = x.data_ptr(), cs.data_ptr(), 192, 45
+    L.check(so.avi_transpose_jobs(two, 2, L.stream_ptr()), "avi_transpose_jobs")
+    torch.cuda.synchronize()
+    assert torch.equal(xt, x.t()) and (cs - x.sum(0)).abs().max().item() < 1e-4
