@@ -271,7 +271,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 template <int D>
 __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
                                                          const float* __restrict__ vp, int Tq, int Tk, int H, int ldq,
-                                                         int ldk, float scale, int bias_mode,
+                                                         int ldk, float scale_in, int bias_mode,
                                                          const float* __restrict__ slopes, int period,
                                                          float* __restrict__ out, int ldo,
                                                          uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo) {
@@ -292,7 +292,11 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
     const float* qbase = qp + (long long)b * Tq * ldq + h * D;
     const float* kbase = kp + (long long)b * Tk * ldk + h * D;
     const float* vbase = vp + (long long)b * Tk * ldk + h * D;
-    const float slope = (bias_mode != 0 && slopes) ? slopes[h] : 0.f;
+    // scores are kept in the log2 domain (log2 e folded into the Q scale and the bias slope): softmax needs one v_exp_f32
+    // per score and no multiply
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float scale = scale_in * LOG2E;
+    const float slope = (bias_mode != 0 && slopes) ? slopes[h] * LOG2E : 0.f;
 
     // ---- Q fragments (B operand of S^T): lane (q = fr, g), scaled, split
     //      D >= 32: Q[q][32 ks + 8 g .. +7];   D = 16: Q[q][4 g .. +3] in elements 0..3
@@ -408,38 +412,48 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
             }
             // ---- online softmax for query fr of each tile (keys 16 t + 4 g + r in this lane)
             bf16x8 ph[2][2], pl[2][2];
+            // masks and biases only where the tile needs them (wave-uniform): a key tile that ends past Tk, any bias
+            // mode, or - causal - a tile that reaches the wave's first query row
+            const bool plain = bias_mode == 0 && j0 + 64 <= Tk;
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int qi = q0 + qt * 16 + fr;
                 float mx = -1.0e30f;
+                if (plain) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = j0 + t * 16 + g * 4 + r;
-                        float sv = s[qt][t][r];
-                        bool valid = j < Tk;
-                        if (bias_mode == 1) {          // inferno TransformerMasking.py:80-98
-                            const int dlt = qi > j ? qi - j : j - qi;
-                            sv -= slope * (float)dlt;
-                        } else if (bias_mode == 2) {   // models/faceformer.py:51-72
-                            valid = valid && (j <= qi);
-                            sv -= slope * (float)((qi - j) / period);
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][t][r]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = j0 + t * 16 + g * 4 + r;
+                            float sv = s[qt][t][r];
+                            bool valid = j < Tk;
+                            if (bias_mode == 1) {          // inferno TransformerMasking.py:80-98
+                                const int dlt = qi > j ? qi - j : j - qi;
+                                sv -= slope * (float)dlt;
+                            } else if (bias_mode == 2) {   // models/faceformer.py:51-72
+                                valid = valid && (j <= qi);
+                                sv -= slope * (float)((qi - j) / period);
+                            }
+                            sv = valid ? sv : -1.0e30f;     // exp2 of it underflows to exactly 0 below: every query
+                            s[qt][t][r] = sv;               // has seen a valid key (key 0) by the end of the first tile
+                            mx = fmaxf(mx, sv);
                         }
-                        sv = valid ? sv : -1.0e30f;
-                        s[qt][t][r] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mn = fmaxf(m[qt], mx);
-                const float corr = __expf(m[qt] - mn);
+                const float corr = __builtin_amdgcn_exp2f(m[qt] - mn);
                 float sum = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = s[qt][t][r] > -1.0e29f ? __expf(s[qt][t][r] - mn) : 0.f;
+                        const float pv = __builtin_amdgcn_exp2f(s[qt][t][r] - mn);
                         s[qt][t][r] = pv;
                         sum += pv;
                     }
