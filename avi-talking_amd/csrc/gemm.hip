@@ -2,7 +2,8 @@
 //
 //   C[z][m][n] = affine(act(sum_k A[z][m*lda+k] * W[z][n][k] + bias[n])) + R[z][m][n]
 //
-// * One workgroup = 256 threads = 4 waves (2 x 2), output tile 128 (m) x BN (n), K step 64.
+// * One workgroup = 256 threads = 4 waves (2 x 2), output tile 128 or 64 (m) x BN = 128 or 64 (n), K step 64; the
+//   smaller shapes serve grids that would not fill the chip (avi_gemm / launch_gemm below).
 // * A (activations, fp32) is staged through registers: 16-B global loads, split on the fly into
 //   bf16 hi (+ lo) parts, written to LDS as 128-B rows with the (row&7)<<4 XOR swizzle so the
 //   ds_read_b128 fragment reads are bank-conflict free (cdna_hip_programming.md T2).
@@ -21,26 +22,28 @@
 
 namespace {
 
-constexpr int BM = 128;
+constexpr int BM = 128;   // rows per tile of the standard instantiation; gemm_kernel<..., 64> halves it
 constexpr int BK = 64;
 constexpr int ROWB = BK * 2;  // bytes per LDS row (bf16)
 
-template <int BN, int NS>
+template <int BN, int NS, int BMT = BM>
 struct GemmSmem {
-    static constexpr int A_BYTES = BM * ROWB;
+    static constexpr int A_BYTES = BMT * ROWB;
     static constexpr int W_BYTES = BN * ROWB;
     static constexpr int TOTAL = NS * (A_BYTES + W_BYTES);
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
-template <int BN, int NS>
+template <int BN, int NS, int BMT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+    constexpr int AI = BMT / 32;     // staging rows per thread (row r0 + 32 i)
+    constexpr int WROWS = BMT / 2;   // rows of a wave (2 x 2 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA0 = smem;
-    char* const sA1 = smem + GemmSmem<BN, NS>::A_BYTES;
-    char* const sW0 = smem + NS * GemmSmem<BN, NS>::A_BYTES;
-    char* const sW1 = sW0 + GemmSmem<BN, NS>::W_BYTES;
+    char* const sA1 = smem + GemmSmem<BN, NS, BMT>::A_BYTES;
+    char* const sW0 = smem + NS * GemmSmem<BN, NS, BMT>::A_BYTES;
+    char* const sW1 = sW0 + GemmSmem<BN, NS, BMT>::W_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
 
     const int z = blockIdx.y;
     const int zo = z / g.z_inner, zi = z - zo * g.z_inner;
@@ -65,9 +68,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
 
     // ---- staging assignment: thread -> (row r0 + 32 i, 16-B chunk c) of a 64-wide K slice
     const int r0 = tid >> 3, c = tid & 7;
-    const float* aptr[4];
+    const float* aptr[AI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
         int m = m0 + r0 + 32 * i;
         m = m < g.M ? m : g.M - 1;  // clamp: rows past M are computed and discarded
         aptr[i] = A + (long long)m * g.lda + c * 8;
@@ -82,12 +85,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
         wlp[i] = (NS == 2) ? Wlo + off : nullptr;
     }
 
-    f32x4 ra[4][2];
+    f32x4 ra[AI][2];
     u32x4 rwh[WI], rwl[WI];
 
     auto load_tile = [&](const int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             ra[i][0] = *reinterpret_cast<const f32x4*>(aptr[i] + k0);
             ra[i][1] = *reinterpret_cast<const f32x4*>(aptr[i] + k0 + 4);
         }
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             const int r = r0 + 32 * i;
             bf16x8 hi, lo;
 #pragma unroll
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
         }
     };
 
-    constexpr int MT = 4;        // 16-row m tiles per wave (64 rows)
+    constexpr int MT = WROWS / 16;   // 16-row m tiles per wave (64 or 32 rows)
     constexpr int NT = BN / 32;  // 16-col n tiles per wave (BN/2 cols)
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
             bf16x8 xh[MT], xl[MT], wh[NT], wl[NT];
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
-                const int row = wm * 64 + b * 16 + fr;
+                const int row = wm * WROWS + b * 16 + fr;
                 xh[b] = *reinterpret_cast<const bf16x8*>(sA0 + swz(row, ch));
                 if (NS == 2) xl[b] = *reinterpret_cast<const bf16x8*>(sA1 + swz(row, ch));
             }
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
         }
     }
 
-    // ---- epilogue: lane holds C[m = m0 + wm*64 + b*16 + fr][n = n0 + wn*BN/2 + a*16 + fq*4 + 0..3]
+    // ---- epilogue: lane holds C[m = m0 + wm*WROWS + b*16 + fr][n = n0 + wn*BN/2 + a*16 + fq*4 + 0..3]
     float* __restrict__ C = g.C + zo * g.sCo + zi * g.sCi;
     const float* __restrict__ bias = g.bias ? g.bias + zo * g.sBo + zi * g.sBi : nullptr;
     const float* __restrict__ R = g.R ? g.R + zo * g.sRo + zi * g.sRi : nullptr;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
             }
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
-            const int m = m0 + wm * 64 + b * 16 + fr;
+            const int m = m0 + wm * WROWS + b * 16 + fr;
             if (m >= g.M) continue;
             float v[4];
 #pragma unroll
@@ -213,19 +216,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
 }
 
 
-template <int BN, int NS>
-int launch_gemm(const AviGemm& g, hipStream_t s) {
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    constexpr int smem = GemmSmem<BN, NS>::TOTAL;
+template <int BN, int NS, int BMT>
+int launch_gemm_tile(const AviGemm& g, hipStream_t s) {
+    const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + BN - 1) / BN;
+    constexpr int smem = GemmSmem<BN, NS, BMT>::TOTAL;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BN, NS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BN, NS, BMT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     dim3 grid(tilesM * tilesN, g.batch, 1);
-    hipLaunchKernelGGL((gemm_kernel<BN, NS>), grid, dim3(256), smem, s, g, tilesM, tilesN);
+    hipLaunchKernelGGL((gemm_kernel<BN, NS, BMT>), grid, dim3(256), smem, s, g, tilesM, tilesN);
     return avi_launch_status();
+}
+
+// 64 x 64 tiles when 128 x 64 tiles still come to at most two workgroups per CU: such launches are bound by the MFMA
+// rate of the workgroups they have, and halving the tile again took 25-40 % off them (squasher 48 -> 29 us, the
+// training step 3.5 -> 3.2 ms).  AVI_GEMM_ROWS64 overrides the tile-count threshold (0 = never).
+template <int BN, int NS>
+int launch_gemm(const AviGemm& g, hipStream_t s) {
+    static const int rows64 = [] { const char* e = getenv("AVI_GEMM_ROWS64"); return e ? atoi(e) : 512; }();
+    const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch;
+    if (BN == 64 && tiles <= rows64) return launch_gemm_tile<BN, NS, 64>(g, s);
+    return launch_gemm_tile<BN, NS, BM>(g, s);
 }
 
 __global__ void pack_split_kernel(const float* __restrict__ W, int N, int K, int N_pad, uint16_t* __restrict__ hi,
@@ -314,7 +328,11 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
         if (pick == 3) return avi_gemm_pp192_launch(g, 256, s);
         return avi_gemm_dma_launch(g, s);
     }
-    const bool narrow = g.N <= 64;
+    // 64-column tiles for narrow outputs and for grids of up to two 128-column workgroups per CU: these launches are
+    // bound by the MFMA rate of the workgroups they have (0.75 us per 128x128x64 step on one CU), so twice the
+    // workgroups of half the width finish 15-35 % sooner (decoder head, time-embedding MLP, the training step's GEMMs)
+    const long long tiles128 = (long long)((g.M + BM - 1) / BM) * ((g.N + 127) / 128) * g.batch;
+    const bool narrow = g.N <= 64 || tiles128 <= 512;
     if (prec == AVI_PREC_BF16X3) return narrow ? launch_gemm<64, 2>(g, s) : launch_gemm<128, 2>(g, s);
     return narrow ? launch_gemm<64, 1>(g, s) : launch_gemm<128, 1>(g, s);
 }

@@ -312,7 +312,11 @@ def gemm_family(kw):
             if c[0] > best[0]:
                 best = c
         return best[1]
-    return "gemm_kernel<128>" if kw["N"] > 64 else "gemm_kernel<64>"
+    M, N, batch = kw["M"], kw["N"], kw.get("batch", 1)             # csrc/gemm.hip: 64-column tiles for narrow outputs and
+    tiles128 = -(-M // 128) * -(-N // 128) * batch                 # small grids, 64 x 64 tiles for the smallest
+    if N > 64 and tiles128 > 512:
+        return "gemm_kernel<128>"
+    return "gemm_kernel<64> (64x64)" if -(-M // 128) * -(-N // 64) * batch <= 512 else "gemm_kernel<64>"
 
 
 def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):

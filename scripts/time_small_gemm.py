@@ -8,7 +8,9 @@ from avi_talking_amd import ops
 dev = torch.device("cuda:0")
 shapes = [("squash 1024x256x2048", 1024, 256, 2048), ("seq_enc 8000x128x768", 8000, 128, 768),
           ("train ff dX 192x128x1024", 192, 128, 1024), ("train to_q 192x640x128", 192, 640, 128),
-          ("time mlp 64x512x512", 64, 512, 512), ("tel ffn 8000x256x256", 8000, 256, 256)]
+          ("time mlp 64x512x512", 64, 512, 512), ("tel ffn 8000x256x256", 8000, 256, 256),
+          ("bert qkv 8000x384x128", 8000, 384, 128), ("flint lin 8192x256x256", 8192, 256, 256),
+          ("dW 512x128x192", 512, 128, 192), ("tel qkv 8000x768x256", 8000, 768, 256)]
 for name, M, N, K in shapes:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(M, K, generator=g).to(dev)
