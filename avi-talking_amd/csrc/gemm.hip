@@ -239,6 +239,7 @@ int launch_gemm(const AviGemm& g, hipStream_t s) {
     static const int rows64 = [] { const char* e = getenv("AVI_GEMM_ROWS64"); return e ? atoi(e) : 512; }();
     const long long tiles = (long long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch;
     // (and whenever the problem has at most 64 rows: the upper half of a 128-row tile would be padding)
+    if (BN == 64 && g.M <= 32 && rows64 > 0) return launch_gemm_tile<BN, NS, 32>(g, s);   // the aligner at 32 rows
     if (BN == 64 && (tiles <= rows64 || (g.M <= 64 && rows64 > 0))) return launch_gemm_tile<BN, NS, 64>(g, s);
     return launch_gemm_tile<BN, NS, BM>(g, s);
 }
