@@ -9,6 +9,7 @@ Device work per layer (pre-LN CLIPEncoderLayer): LayerNorm emitting split bf16 p
 the ping-pong GEMM -> causal head-dim-64 attention on the matrix cores -> out_proj (+residual) -> LayerNorm planes ->
 fc1 + quick_gelu (planes out) -> fc2 (+residual).  Nothing here falls back to the CPU.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -25,6 +26,7 @@ class FrozenCLIPEmbedder:
         self.eps = eps
         self.max_length = max_length
         self.tokenizer = tokenizer
+        self.small_rows = int(os.environ.get("AVI_CLIP_SMALL_ROWS", "3072"))
         # checkpoints of CLIPTextModel carry a "text_model." prefix; newer transformers state_dicts drop it
         w = {(k[len("text_model."):] if k.startswith("text_model.") else k):
              v.detach().to(self.device, torch.float32).contiguous()
@@ -77,6 +79,19 @@ class FrozenCLIPEmbedder:
         B, T = ids.shape
         C, H = self.hidden, self.heads
         h = ops.embed_tokens(ids, self.tok, self.pos)
+        if B * T <= self.small_rows:
+            # few rows: the 128-row plane-operand tiles would cover a quarter of the chip (60-80 tiles for the 768-wide
+            # projections at 32 prompts); the fp32-operand GEMM has 64 x 64 tiles for such grids
+            for ly in self.layers:
+                x = ops.layernorm(h, *ly.ln1, eps=self.eps)
+                qkv = ops.linear(x, ly.qkv)
+                att = ops.attention(qkv, qkv[..., C:], qkv[..., 2 * C:], H, 64, 3 * C, 3 * C, T, T, B, 64 ** -0.5,
+                                    bias_mode=2, slopes=self.zero_slopes, period=1)
+                h = ops.linear(att, ly.out, residual=h)
+                x = ops.layernorm(h, *ly.ln2, eps=self.eps)
+                f = ops.linear(x, ly.fc1, act=ops.ACT_QUICK_GELU)
+                h = ops.linear(f, ly.fc2, residual=h)
+            return ops.layernorm(h, *self.final, eps=self.eps)
         for ly in self.layers:
             _, xp = ops.layernorm_planes(h, *ly.ln1, eps=self.eps, want_f32=False)
             qkv = ops.linear_planes(xp, ly.qkv)                                          # (B, T, 3C) fp32

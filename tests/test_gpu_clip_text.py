@@ -47,6 +47,22 @@ def test_clip_text_matches_oracle(gpu, embedder, clip_w, B, T):
     assert err < TOL
 
 
+def test_clip_text_plane_operand_path(gpu, clip_w, monkeypatch):
+    """Above ~3000 rows the layers run on the plane-operand ping-pong GEMMs (forced here at 5 x 77 rows): same parity
+    bar, and agreement with the few-rows path."""
+    from avi_talking_amd.host.clip_text import FrozenCLIPEmbedder
+    from oracle import clip_text as OC
+    monkeypatch.setenv("AVI_CLIP_SMALL_ROWS", "0")
+    big = FrozenCLIPEmbedder.from_state_dict(clip_w, device=gpu)
+    monkeypatch.setenv("AVI_CLIP_SMALL_ROWS", "100000")
+    small = FrozenCLIPEmbedder.from_state_dict(clip_w, device=gpu)
+    ids = torch.randint(0, 49408, (5, 77), generator=torch.Generator().manual_seed(21))
+    ref = OC.clip_text_forward(clip_w, ids)
+    a, b = big(ids), small(ids)
+    assert (a.cpu() - ref).abs().max().item() < TOL and (b.cpu() - ref).abs().max().item() < TOL
+    assert (a - b).abs().max().item() < 2e-4
+
+
 def test_clip_text_is_causal_and_batch_independent(gpu, embedder):
     """Position t depends on tokens <= t only, and a row's result does not depend on its batch mates (bit-exact)."""
     g = torch.Generator().manual_seed(5)
