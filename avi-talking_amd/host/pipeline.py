@@ -45,7 +45,7 @@ class SamplingPipeline:
         B, N = pcm.shape
         T = N // 640
         cur = torch.cuda.current_stream(self.device)
-        # 1. Aligner MLP on the launch stream, before anything else (0.25 ms: split-K launches that stream the 300 MB
+        # 1. Aligner MLP on the launch stream, before anything else (0.17 ms: split-K launches that stream the 300 MB
         #    of weights at HBM speed).  On the second stream its ten launches each queue behind resident GEMM
         #    workgroups of the audio branch and the sampler starts late (+0.4 ms per step, measured);
         #    AVI_ALIGNER_SIDE=1 selects that arrangement for tests/test_gpu_fullsize.py, which pins that overlapping
