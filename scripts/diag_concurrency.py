@@ -9,6 +9,10 @@ serially is bit-exact.  What was ruled in and out (MI355X, ROCm 7.2):
     LayerNorm (SIDE=ln): clean; GEMM without its global loads (SIDE=gemm_noload): still wrong -> matrix-core waves
     sharing the victim's SIMDs are required (the 100-step sampler holds its CUs exclusively and never did harm);
   * all accumulators consumed before the aggressor's waves end (GM=128), 80 idle cycles before its epilogue: still wrong;
+  * the aggressor's SHAPE matters: 128-row tiles (gemm_kernel<128,2,128> 230 VGPRs, <64,2,128> 146 VGPRs per lane:
+    AVI_GEMM_ROWS64=0 selects the latter) corrupt the victim in every run, the 32-row-tile kernel the dispatcher now
+    picks for this problem (~100 VGPRs) never did - run this script with AVI_GEMM_ROWS64=0 to see the failure on a
+    packed build;
   * victim without LDS staging, with non-temporal stores, second stream at normal priority (PRIO=0): still wrong;
   * victim (elementwise.hip) compiled without v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: CLEAN, 12 of 12 runs;
   * a reduced stand-alone pair (inline-assembly v_pk_fma_f32 chains, with and without op_sel, next to short launches of

@@ -85,3 +85,22 @@ def test_config1_aligner_overlapping_the_audio_branch(gpu, monkeypatch):
         rep = pipe.replay()
         torch.cuda.synchronize()
         assert torch.equal(rep["predicted_exp"], exp) and torch.equal(rep["predicted_jaw"], jaw)
+
+
+
+def test_two_stream_reproduction_is_clean(gpu):
+    """scripts/diag_concurrency.py with the aggressor shape that corrupted conv layer 0 when the library contained
+    packed-FP32 instructions (128-row GEMM tiles: AVI_GEMM_ROWS64=0; the variable is read once per process, hence
+    the subprocess): every iteration must report zero differing values.  With `AVI_PACKED_FP32=1 build.py` this fails
+    in every iteration."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVI_GEMM_ROWS64="0", SIDE="gemm")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_concurrency.py"), "overlap"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    counts = [int(m) for m in re.findall(r"iter \d+ \[overlap\].* n (\d+)", out.stdout)]
+    assert len(counts) == 4 and all(c == 0 for c in counts), out.stdout[-2000:]
