@@ -15,10 +15,10 @@ serially is bit-exact.  What was ruled in and out (MI355X, ROCm 7.2):
     packed build;
   * victim without LDS staging, with non-temporal stores, second stream at normal priority (PRIO=0): still wrong;
   * victim (elementwise.hip) compiled without v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: CLEAN, 12 of 12 runs;
-  * a reduced stand-alone pair (inline-assembly v_pk_fma_f32 chains, with and without op_sel, next to short launches of
-    register-only MFMA loops) did NOT reproduce it: the trigger needs more of the real kernels (the GEMM's 232
-    registers per lane, its LDS fragment reads, the victim's LDS / global traffic), which is why this script keeps
-    using the library's own kernels.
+  * a reduced stand-alone pair (inline-assembly v_pk_fma_f32 / v_pk_mul_f32 chains, with and without op_sel, next to
+    short launches of register-only MFMA loops holding 24 or 184 VGPRs per lane) did NOT reproduce it: the register
+    footprint alone is not the trigger; it needs more of the real kernels (the GEMM's LDS tiles and fragment reads,
+    the victim's LDS / global traffic), which is why this script keeps using the library's own kernels.
 So the library is built without packed-FP32 instructions and this script prints zero differences.
   python scripts/diag_concurrency.py overlap | serial      (PRIO=0 for a normal-priority second stream)"""
 import sys, os
