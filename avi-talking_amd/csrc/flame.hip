@@ -259,10 +259,19 @@ __global__ __launch_bounds__(256) void flame_pack_basis_kernel(const AviFlameBas
     lo[i] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
 }
 
-// grid (ceil(V/64), B), block 256: wave w owns vertices [vt*16, vt*16+16), vt = 4*blockIdx.x + w, and walks the
-// frames of clip blockIdx.y in tiles of 16.  No LDS, no barriers (a wave past the last vertex tile just leaves).
-// MFMA operand roles as in gemm.hip: first operand = rows of the "n" matrix (vertices), second = rows of the "m"
-// matrix (frames); lane (fr, fq) receives D[frame f0+fr][vertex vt*16 + fq*4 + 0..3] per coordinate plane.
+// grid (ceil(V/64), B), block 256: wave w owns vertices [vt*16, vt*16+16), vt = 4*blockIdx.x + w, and walks the frames of
+// clip blockIdx.y in tiles of 16.  MFMA operand roles as in gemm.hip: first operand = rows of the "n" matrix (vertices),
+// second = rows of the "m" matrix (frames); lane (fr, fq) receives D[frame f0+fr][vertex vt*16 + fq*4 + 0..3] per
+// coordinate plane.  The per-tile operands of the four waves (they work on the SAME 16 frames of the clip) are
+// fetched once per workgroup by LDS-DMA, one frame tile ahead: the coefficient planes (2 x 32 KP bytes) and the 16 x 240 B
+// of transforms of tile t+1 are requested right after the barrier that opens tile t and land under its MFMAs, skinning
+// and stores (with per-wave global loads instead, every wave waited out the L2 latency twice per tile: 329 -> 265 us).
+//   vmcnt: the DMA requests of a wave are older than the three output stores of the tile, so `s_waitcnt vmcnt(3)` at
+//   the top of the next tile means "my DMA pieces have landed"; the barrier that follows makes that true for all waves
+//   and also orders the previous tile's LDS reads before the buffer is refilled (two buffers, one barrier per tile).
+typedef __attribute__((address_space(3))) void flame_lds_void;
+typedef const __attribute__((address_space(1))) void flame_gbl_void;
+
 template <int KS>
 __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kernel(const AviFlameBasis fb,
                                                                    const float* __restrict__ v_shaped,
@@ -270,12 +279,46 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                                                                    const uint16_t* __restrict__ clo,
                                                                    const float* __restrict__ xf, int T, int Vp,
                                                                    float* __restrict__ verts) {
-    constexpr int KP = KS * 32, SLAB_ROW = 52;   // 48 floats per frame row + 4 of padding (bank spread of the writes)
+    constexpr int KP = KS * 32, SLAB_ROW = 52;
+    constexpr int CROW = KP * 2;                       // bytes of one frame's coefficients in a plane (192 / 320)
+    constexpr int CPL = 16 * CROW;                     // one plane of a 16-frame tile = KS KiB
+    constexpr int XROW = NJ * 12 * 4;                  // 240 B of transforms per frame
+    constexpr int BUF = 2 * CPL + 4096;                // [coef hi | coef lo | transforms (3840 B used)]
+    constexpr int NCH = 2 * KS + 4;                    // 1-KiB DMA pieces per tile
+    __shared__ __attribute__((aligned(16))) char stage[2 * BUF];
     __shared__ __attribute__((aligned(16))) float slabs[4 * 16 * SLAB_ROW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int vt = blockIdx.x * 4 + wave, b = blockIdx.y;
-    if (vt * 16 >= fb.V) return;
+    const int b = blockIdx.y;
+    const int vt_raw = blockIdx.x * 4 + wave;
+    const bool live = vt_raw * 16 < fb.V;              // wave-uniform; a spare wave still fetches and synchronises
+    const int vt = live ? vt_raw : 0;
+    const int fbeg = b * T, fend = fbeg + T;
+
+    // piece c of a tile: 64 lanes x 16 B of [coef hi | coef lo | transforms]; rows past the clip re-read its last frame
+    auto issue = [&](int f0, int buf) __attribute__((always_inline)) {
+        for (int c = wave; c < NCH; c += 4) {
+            const char* base;
+            int row_bytes, o;
+            if (c < 2 * KS) {
+                base = reinterpret_cast<const char*>(c < KS ? chi : clo);
+                row_bytes = CROW;
+                o = (c < KS ? c : c - KS) * 1024 + lane * 16;
+            } else {
+                base = reinterpret_cast<const char*>(xf);
+                row_bytes = XROW;
+                o = (c - 2 * KS) * 1024 + lane * 16;
+            }
+            const int rf = o / row_bytes, within = o - rf * row_bytes;
+            const int f = f0 + rf < fend ? f0 + rf : fend - 1;
+            const char* src = base + (long long)f * row_bytes + within;
+            char* dst = stage + buf * BUF + (c < 2 * KS ? c * 1024 : 2 * CPL + (c - 2 * KS) * 1024);
+            __builtin_amdgcn_global_load_lds((flame_gbl_void*)src, (flame_lds_void*)dst, 16, 0, 0);
+        }
+    };
+    issue(fbeg, 0);
+
     bf16x8 bh[3][KS], bl[3][KS];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -289,24 +332,30 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
     float w[4][NJ], vs[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int vi = vb + j < fb.V ? vb + j : fb.V - 1;   // vertices past V: computed from a valid row, never stored
+        const int vi = vb + j < fb.V ? vb + j : fb.V - 1;
 #pragma unroll
         for (int q = 0; q < NJ; ++q) w[j][q] = fb.lbs_weights[(long long)vi * NJ + q];
 #pragma unroll
         for (int c = 0; c < 3; ++c) vs[j][c] = v_shaped[(long long)b * n3 + vi * 3 + c];
     }
-    const int fbeg = b * T, fend = fbeg + T;
-    for (int f0 = fbeg; f0 < fend; f0 += 16) {
-        const int f = f0 + fr;
-        const int fc = f < fend ? f : fend - 1;          // rows past the clip are computed and dropped
+    const bool full = vt * 16 + 16 <= fb.V;            // wave-uniform
+    int buf = 0;
+    for (int f0 = fbeg; f0 < fend; f0 += 16, buf ^= 1) {
+        // my pieces of this tile have landed (only the previous tile's three output stores may still be in flight)
+        if (live && full && f0 != fbeg) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (f0 + 16 < fend) issue(f0 + 16, buf ^ 1);
+        if (!live) continue;
+        const char* sb = stage + buf * BUF;
         f32x4 acc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const long long o = (long long)fc * KP + ks * 32 + fq * 8;
-            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(chi + o);
-            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(clo + o);
+            const int o = fr * CROW + (ks * 4 + fq) * 16;
+            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(sb + o);
+            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(sb + CPL + o);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[c][ks], ch, acc[c], 0, 0, 0);
@@ -314,9 +363,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c][ks], ch, acc[c], 0, 0, 0);
             }
         }
-        // skinning (lbs.py:215-235): the 5 x (3x4) transforms of this lane's frame, blended per vertex
-        // (row r of all five transforms at a time: 20 live registers instead of 60)
-        const f32x4* ap = reinterpret_cast<const f32x4*>(xf + (long long)fc * (NJ * 12));
+        const f32x4* ap = reinterpret_cast<const f32x4*>(sb + 2 * CPL + fr * XROW);
         float px[4], py[4], pz[4], o[12];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -337,25 +384,34 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                 o[j * 3 + r] = t[0] * px[j] + t[1] * py[j] + t[2] * pz[j] + t[3];
             }
         }
-        if (vt * 16 + 16 <= fb.V) {
-            // Full vertex tile: the wave's 16 frames x 192 B go through a private LDS slab so that every store
-            // instruction writes whole 192-byte runs (12 consecutive lanes = one frame's 16 vertices) instead of 16-byte
-            // pieces 48 bytes apart (which held the store phase to 3.4 TB/s).
+        const int f = f0 + fr;
+        if (full) {
             float* slab = slabs + wave * (16 * SLAB_ROW);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 *reinterpret_cast<f32x4*>(slab + fr * SLAB_ROW + fq * 12 + 4 * i) =
                     (f32x4){o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, other lanes' rows
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 val[3];
+            int fl[3], piece[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int cidx = i * 64 + lane, fl = cidx / 12, piece = cidx - fl * 12;
-                const f32x4 val = *reinterpret_cast<const f32x4*>(slab + fl * SLAB_ROW + piece * 4);
-                if (f0 + fl < fend)
-                    *reinterpret_cast<f32x4u*>(verts + ((long long)(f0 + fl) * fb.V + vt * 16) * 3 + piece * 4) = val;
+                const int cidx = i * 64 + lane;
+                fl[i] = cidx / 12;
+                piece[i] = cidx - fl[i] * 12;
+                val[i] = *reinterpret_cast<const f32x4*>(slab + fl[i] * SLAB_ROW + piece[i] * 4);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next tile rewrites it
-        } else if (f < fend) {   // last, partial vertex tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // exactly three store instructions per lane and tile (the vmcnt(3) above counts on it): frames past the
+            // clip are redirected to this lane's last valid destination, which receives the same value again
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int ff = f0 + fl[i] < fend ? f0 + fl[i] : -1;
+                float* dst = verts + ((long long)(ff >= 0 ? ff : f0) * fb.V + vt * 16) * 3 + piece[i] * 4;
+                if (ff < 0) val[i] = *reinterpret_cast<const f32x4*>(slab + 0 * SLAB_ROW + piece[i] * 4);
+                *reinterpret_cast<f32x4u*>(dst) = val[i];
+            }
+        } else if (f < fend) {
             float* op = verts + ((long long)f * fb.V + vb) * 3;
 #pragma unroll
             for (int i = 0; i < 12; ++i)
