@@ -312,11 +312,18 @@ def gemm_family(kw):
             if c[0] > best[0]:
                 best = c
         return best[1]
-    M, N, batch = kw["M"], kw["N"], kw.get("batch", 1)             # csrc/gemm.hip: 64-column tiles for narrow outputs and
-    tiles128 = -(-M // 128) * -(-N // 128) * batch                 # small grids, 64 x 64 tiles for the smallest
+    # fp32-operand kernel gemm_kernel<BN, NS, BM> (csrc/gemm.hip avi_gemm / launch_gemm): 64-column tiles for narrow
+    # outputs and small grids, 64- or 32-row tiles for the smallest
+    M, N, batch = kw["M"], kw["N"], kw.get("batch", 1)
+    ns = 2 if (kw.get("prec", 3) & 0xff) == 3 else 1
+    tiles128 = -(-M // 128) * -(-N // 128) * batch
     if N > 64 and tiles128 > 512:
-        return "gemm_kernel<128>"
-    return "gemm_kernel<64> (64x64)" if -(-M // 128) * -(-N // 64) * batch <= 512 else "gemm_kernel<64>"
+        return f"gemm_kernel<128, {ns}, 128>"
+    if M <= 32:
+        return f"gemm_kernel<64, {ns}, 32>"
+    if -(-M // 128) * -(-N // 64) * batch <= 512 or M <= 64:
+        return f"gemm_kernel<64, {ns}, 64>"
+    return f"gemm_kernel<64, {ns}, 128>"
 
 
 def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
@@ -372,10 +379,12 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
     def describe(name):
         ms, fl, n = fam[name]
         ach = fl / (ms * 1e-3) / 1e12
-        base = name.split(" ")[0].split("<")[0]
-        tag = name.split("<")[1].split(">")[0] if "<" in name else ""
-        tag = {"NT=3": ", 3>", "NT=4": ", 4>"}.get(tag, tag)
-        t = next((v for k, v in traffic.items() if k.startswith(base) and (tag in k if tag else True)), None)
+        t = traffic.get(name)                       # fp32-operand kernels carry their exact kernel name
+        if t is None:
+            base = name.split(" ")[0].split("<")[0]
+            tag = name.split("<")[1].split(">")[0] if "<" in name else ""
+            tag = {"NT=3": ", 3>", "NT=4": ", 4>"}.get(tag, tag)
+            t = next((v for k, v in traffic.items() if k.startswith(base) and (tag in k if tag else True)), None)
         return {"bound": "mfma", "kernel": f"{name} (bf16 MFMA 16x16x32, {ns} MFMA per product)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),
