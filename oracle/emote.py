@@ -18,8 +18,12 @@ Configuration: talkinghead_conf/model/sequence_decoder/bertprior_wild.yaml (feat
 motion_prior_conf l2l_decoder.yaml / l2l_sizes.yaml (dim 256, ff 384, 8 heads, quant_factor 3,
 alibi_future).  BatchNorm runs in eval mode (FaceFormerDecoder.py:1061-1067 keeps the prior in eval).
 
-PARITY UNPINNED beyond the attention masks: the inferno modules cannot be imported here
-(pytorch_lightning, omegaconf, munch, pytorch3d absent); masks are pinned against the importable
+Pinned (tests/test_oracle_golden.py::test_emote_oracle_matches_reference, tests/golden/emote.npz) against the
+reference's OWN classes run unmodified in the build container - LinearSequenceEncoder, LinearEmotionCondition,
+BertPriorDecoder.forward/_style/_decode/_apply_motion_prior, StackLinearSquash, MotionPrior.decoding_step and
+L2lDecoder - to 2e-6 (tests/golden/make_golden.py: functional stand-ins for omegaconf/munch/pytorch_lightning,
+and the MultiheadAttention fast path of torch >= 1.12 switched off: the reference pins torch 1.9, which has none,
+and the fast path mishandles L2lDecoder's (B*H,T,T) float mask).  The masks are also pinned against the importable
 TransformerMasking.py (tests/golden/masks.npz).
 """
 import math

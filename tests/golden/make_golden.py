@@ -18,6 +18,23 @@ What is pinned:
   * flame.npz        inferno ``utils/lbs.py`` ``lbs`` (imported as is: pure torch) on the synthetic FLAME basis of
                      avi_talking_amd.weights.make_flame_basis, with the pose assembly of ``FLAME.forward``
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
+  * emote.npz        inferno ``LinearSequenceEncoder`` (SequenceEncoders.py:180-197), ``LinearEmotionCondition``
+                     (FaceFormerDecoder.py:186-268), ``BertPriorDecoder.forward`` -> ``FeedForwardDecoder.forward/_style``,
+                     ``_decode``, ``_post_prediction`` -> ``_apply_motion_prior`` (:598-682,1104-1224) with
+                     ``StackLinearSquash`` (:967-985), ``MotionPrior.decoding_step`` / ``decompose_sequential_output``
+                     (MotionPrior.py:316-329,371-375) and ``L2lDecoder`` (L2lMotionPrior.py:361-495): the reference's
+                     own classes, METHODS RUN UNMODIFIED.  ``L2lDecoder``, ``StackLinearSquash``, ``LinearSequenceEncoder``
+                     and ``LinearEmotionCondition`` are built by their own constructors from the yaml values
+                     (bertprior_wild.yaml, l2l_decoder.yaml, l2l_sizes.yaml); ``BertPriorDecoder`` / ``L2lVqVae`` are built
+                     with ``__new__`` + hand-attached submodules (their ``__init__`` loads a trained FLINT checkpoint and
+                     the licensed FLAME model from cluster paths).  The FLAME vertex post-processor (out of scope here,
+                     row 8f-1 has its own fixture) is a stub returning zero vertices.  Absent packages get FUNCTIONAL
+                     stand-ins for the few symbols the executed path touches (``OmegaConf.to_container``, ``munchify``,
+                     ``open_dict``, ``pl.LightningModule = nn.Module``); everything else is a MagicMock.
+                     ``torch.backends.mha.set_fastpath_enabled(False)``: torch >= 1.12 routes an eval-mode
+                     ``TransformerEncoderLayer`` through a fused fast path that mishandles the (B*H,T,T) FLOAT mask of
+                     ``L2lDecoder`` (0.96 max-abs off the mathematical definition on this input); the reference pins
+                     torch 1.9, which has no fast path, so the slow path IS the reference behaviour.
 Absent packages (cv2, easydict, omegaconf, torchvision, clip, dalle2_pytorch, gdl, pirender ...) are
 replaced by MagicMock modules so the reference files import; none of the mocked symbols is on the
 executed path.  The dalle2-based prior classes cannot be executed (dalle2_pytorch absent): unpinned.
@@ -218,6 +235,181 @@ def gen_flame():
     print("flame.npz: verts", tuple(v.shape), "slice", tuple(v[:, idx].shape))
 
 
+class _Munch(dict):
+    """Functional stand-in for munch.Munch / an OmegaConf DictConfig node: a dict with attribute access."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _munchify(x):
+    if isinstance(x, dict):
+        return _Munch({k: _munchify(v) for k, v in x.items()})
+    if isinstance(x, (list, tuple)):
+        return type(x)(_munchify(v) for v in x)
+    return x
+
+
+def _to_container(x, **kw):
+    if isinstance(x, dict):
+        return {k: _to_container(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_to_container(v) for v in x]
+    return x
+
+
+def import_inferno():
+    """Import the reference's EMOTE / FLINT modules from third_party/inferno as they lie."""
+    import contextlib
+    inf = os.path.join(REF, "third_party/inferno/inferno")
+    oc = types.ModuleType("omegaconf")
+    oc.OmegaConf = type("OmegaConf", (), {"to_container": staticmethod(_to_container)})
+    oc.DictConfig = _Munch
+    oc.open_dict = lambda cfg: contextlib.nullcontext(cfg)
+    sys.modules["omegaconf"] = oc
+    mu = types.ModuleType("munch")
+    mu.Munch, mu.munchify = _Munch, _munchify
+    sys.modules["munch"] = mu
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = torch.nn.Module
+    sys.modules["pytorch_lightning"] = pl
+    for n in ("pytorch3d", "pytorch3d.transforms"):
+        sys.modules[n] = MagicMock()
+    for name, sub in (("inferno", ""), ("inferno.models", "models"), ("inferno.models.temporal", "models/temporal"),
+                      ("inferno.models.temporal.motion_prior", "models/temporal/motion_prior"),
+                      ("inferno.models.talkinghead", "models/talkinghead"), ("inferno.utils", "utils"),
+                      ("inferno.layers", "layers"), ("inferno.layers.losses", "layers/losses")):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(inf, sub)]
+        sys.modules[name] = m
+    # modules that drag in renderers / datasets / pytorch3d and are not on the executed path
+    for n in ("inferno.layers.losses.RotationLosses", "inferno.models.MLP", "inferno.models.IO", "inferno.utils.other",
+              "inferno.models.temporal.BlockFactory", "inferno.utils.ValueScheduler"):
+        sys.modules[n] = MagicMock()
+    import importlib
+    return (importlib.import_module("inferno.models.temporal.motion_prior.L2lMotionPrior"),
+            importlib.import_module("inferno.models.talkinghead.FaceFormerDecoder"),
+            importlib.import_module("inferno.models.temporal.SequenceEncoders"))
+
+
+def build_reference_emote(n_identities=32, n_shape=300):
+    """The reference's EMOTE head + FLINT decoder as a module tree with the TalkingHeadBase attribute names
+    (``sequence_encoder``, ``sequence_decoder``) so that make_emote_weights() loads with strict=True."""
+    nn = torch.nn
+    L2l, FFD, SE = import_inferno()
+    torch.backends.mha.set_fastpath_enabled(False)      # see the module docstring
+    # motion_prior_conf/model/sequence_decoder/l2l_decoder.yaml + sizes/l2l_sizes.yaml
+    dcfg = _munchify(dict(type="L2lDecoder", num_layers=1, feature_dim=256, intermediate_size=384, nhead=8, dropout=0.0,
+                          activation="gelu", positional_encoding=dict(type="none"),
+                          temporal_bias=dict(type="alibi_future", max_len=600), last_layer_init=False))
+    sizes = _munchify(dict(quant_factor=3, sequence_length=32, quant_sequence_length=4))
+    prior = L2l.L2lVqVae.__new__(L2l.L2lVqVae)
+    nn.Module.__init__(prior)
+    prior.cfg = _munchify(dict(model=dict(sequence_components=dict(exp=50, jaw="rot"), rotation_representation="aa",
+                                          sizes=sizes)))
+    prior.motion_decoder = L2l.L2lDecoder(dcfg, sizes, 53)
+    prior.motion_quantizer = None
+    prior.motion_encoder = None                           # BertPriorDecoder.__init__ discards it (:1025)
+
+    def flame_post(rec_batch, input_key=None, output_prefix="", with_grad=True):   # FLAME vertices: out of scope
+        B, T = rec_batch["gt_exp"].shape[:2]
+        rec_batch[output_prefix + "vertices"] = torch.zeros(B, T, 6)
+        return rec_batch
+    prior.postprocessor = flame_post
+    # talkinghead_conf/model/sequence_decoder/bertprior_wild.yaml
+    style_cfg = _munchify(dict(type="emotion_linear", use_shape=True, shape_dim=n_shape, use_video_expression=False,
+                               gt_expression_label=True, gt_expression_intensity=True, n_intensities=3,
+                               gt_expression_identity=True, n_identities=n_identities, disentangle_identity=False,
+                               use_expression=False, n_expression=8, use_valence=False, use_arousal=False,
+                               use_emotion_feature=False, use_bias=True))
+    cfg = _munchify(dict(type="BertPriorDecoder", num_layers=1, feature_dim=128, nhead=8, dropout=0.25, activation="gelu",
+                         squash_before=False, squash_after=True, squash_type="stack_linear", post_bug_fix=True,
+                         positional_encoding=dict(type="none"), style_embedding=style_cfg,
+                         motion_prior=dict(trainable=False), flame=dict(n_shape=n_shape)))
+    dec = FFD.BertPriorDecoder.__new__(FFD.BertPriorDecoder)
+    nn.Module.__init__(dec)
+    dec.cfg = cfg
+    dec.style_type = cfg.style_embedding
+    dec.obj_vector = FFD.LinearEmotionCondition(style_cfg, output_dim=128)          # style_from_cfg (:87-97)
+    dec.style_op = "add"
+    dec.PE = None                                                                 # positional_encoding.type none
+    layer = nn.TransformerEncoderLayer(d_model=128, nhead=8, dim_feedforward=128, activation="gelu", dropout=0.25,
+                                       batch_first=True)                          # :995-1001
+    dec.bert_decoder = nn.TransformerEncoder(layer, num_layers=1)
+    dec.post_bug_fix = True
+    dec.temporal_bias_type, dec.biased_mask = "none", None
+    dec.motion_prior = prior
+    dec.latent_frame_size = 8                                                     # 2 ** quant_factor
+    dec.squasher = None
+    dec.decoder = nn.Linear(128, 256)                                             # :1034
+    dec.squasher_2 = FFD.StackLinearSquash(256, 8, 256)                           # _create_squasher (:1049-1055)
+
+    class Flame(nn.Module):
+        def forward(self, shape, exp):
+            return torch.zeros(shape.shape[0], 2, 3), None, None
+    dec.flame = Flame()
+    root = nn.Module()
+    root.sequence_encoder = SE.LinearSequenceEncoder(_munchify(dict(feature_dim=128, input_feature_dim=768)))
+    root.sequence_decoder = dec
+    print(root.load_state_dict(W.make_emote_weights(1, n_identities, n_shape), strict=True))
+    return root.eval()
+
+
+def run_reference_emote(root, feat, style_emb=None, sample_extra=None):
+    """TalkingHeadBase.forward after forward_audio (:531-553): sequence encoder, then the decoder's own forward."""
+    B, T = feat.shape[:2]
+    sample = {"fused_feature": feat, "processed_audio": feat, "raw_audio": torch.zeros(B, T, 640),
+              "template": torch.zeros(B, 6), "gt_shape": torch.zeros(B, 300)}
+    sample.update(sample_extra or {})
+    with torch.no_grad():
+        sample = root.sequence_encoder(sample, input_key="fused_feature")
+        sample = root.sequence_decoder(sample, style_emb=style_emb, is_external_style_emb=style_emb is not None)
+    return sample
+
+
+def gen_emote():
+    root = build_reference_emote()
+    out = {}
+    for tag, B, T in (("a", 2, 250), ("b", 1, 61), ("c", 3, 8)):      # the shapes of tests/test_gpu_emote.py
+        g = torch.Generator().manual_seed(31)
+        feat, style = torch.randn(B, T, 768, generator=g), torch.randn(B, 1, 128, generator=g) * 0.5
+        s = run_reference_emote(root, feat, style)
+        assert s["predicted_exp"].shape == (B, T, 50) and s["predicted_jaw"].shape == (B, T, 3)
+        out[f"{tag}_shape"] = np.array([B, T])
+        out[f"{tag}_seq_encoder_output"] = s["seq_encoder_output"][:, ::7, ::5].numpy()
+        out[f"{tag}_latent"] = s["prior_input_sequence"].numpy()
+        out[f"{tag}_exp"], out[f"{tag}_jaw"] = s["predicted_exp"].numpy(), s["predicted_jaw"].numpy()
+    # per-frame (B,T,128) external style, and the style from the sample's own one-hot conditions
+    B, T = 2, 25
+    g = torch.Generator().manual_seed(41)
+    feat = torch.randn(B, T, 768, generator=g)
+    style_t = torch.randn(B, T, 128, generator=g) * 0.5
+    one_hot = torch.nn.functional.one_hot
+    cond = {"gt_expression_label_condition": one_hot(torch.tensor([3, 5]), 8)[:, None].expand(B, T, 8),
+            "gt_expression_intensity_condition": one_hot(torch.tensor([2, 0]), 3)[:, None].expand(B, T, 3),
+            "gt_expression_identity_condition": one_hot(torch.tensor([7, 30]), 32),      # (B, N): expanded by the module
+            "gt_shape": torch.randn(B, 300, generator=g), "gt_vertices": torch.zeros(B, T, 6)}
+    s = run_reference_emote(root, feat, style_t)
+    out["t_exp"], out["t_jaw"] = s["predicted_exp"].numpy(), s["predicted_jaw"].numpy()
+    with torch.no_grad():
+        sample = dict(cond, seq_encoder_output=feat[..., :128])
+        out["own_style"] = root.sequence_decoder(sample, only_style_emb=True).numpy()
+    s = run_reference_emote(root, feat, None, cond)
+    out["own_exp"], out["own_jaw"] = s["predicted_exp"].numpy(), s["predicted_jaw"].numpy()
+    # L2lDecoder alone on a latent sequence (FLINT decoder, L2lMotionPrior.py:460-495)
+    z = torch.randn(2, 5, 256, generator=torch.Generator().manual_seed(43))
+    with torch.no_grad():
+        out["flint_z_out"] = root.sequence_decoder.motion_prior.motion_decoder(
+            {"encoded_features": z}, input_key="encoded_features")["decoded_sequence"].numpy()
+    np.savez_compressed(os.path.join(HERE, "emote.npz"), **out)
+    print("emote.npz:", {k: v.shape for k, v in out.items()})
+
+
 def gen_clip_text():
     """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
     openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
@@ -245,12 +437,13 @@ def gen_clip_text():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text"):      # regenerate only one fixture
-        {"flame": gen_flame, "clip_text": gen_clip_text}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote"):      # regenerate only one fixture
+        {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote}[sys.argv[1]]()
         sys.exit(0)
     gen_flame()
     gen_clip_text()
     gen_wav2vec2()
+    gen_emote()
     ff, dp = import_reference_models()
     gen_masks(ff)
     gen_brain(dp)

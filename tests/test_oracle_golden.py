@@ -76,6 +76,66 @@ def test_faceformer_predict_matches_reference(D):
     assert np.abs(cached.numpy() - ref).max() < 5e-5
 
 
+EMOTE_SHAPES = {"a": (2, 250), "b": (1, 61), "c": (3, 8)}
+
+
+def emote_inputs(tag):
+    """The seeded inputs tests/golden/make_golden.py::gen_emote fed to the reference classes."""
+    B, T = EMOTE_SHAPES[tag]
+    g = torch.Generator().manual_seed(31)
+    return torch.randn(B, T, 768, generator=g), torch.randn(B, 1, 128, generator=g) * 0.5
+
+
+def emote_condition_inputs():
+    B, T = 2, 25
+    g = torch.Generator().manual_seed(41)
+    feat = torch.randn(B, T, 768, generator=g)
+    style_t = torch.randn(B, T, 128, generator=g) * 0.5
+    oh = torch.nn.functional.one_hot
+    expr = oh(torch.tensor([3, 5]), 8)[:, None].expand(B, T, 8)
+    inten = oh(torch.tensor([2, 0]), 3)[:, None].expand(B, T, 3)
+    ident = oh(torch.tensor([7, 30]), 32)[:, None].expand(B, T, 32)
+    shape = torch.randn(B, 300, generator=g)
+    return feat, style_t, expr, inten, ident, shape
+
+
+@pytest.mark.parametrize("tag", sorted(EMOTE_SHAPES))
+def test_emote_oracle_matches_reference(tag):
+    """oracle/emote.py against the reference's own BertPriorDecoder / L2lDecoder / StackLinearSquash /
+    LinearSequenceEncoder classes run unmodified (tests/golden/emote.npz)."""
+    g = _load("emote.npz")
+    w = W.make_emote_weights(1)
+    feat, style = emote_inputs(tag)
+    assert list(g[tag + "_shape"]) == list(feat.shape[:2])
+    r = OE.forward(w, feat, style, return_intermediates=True)
+    assert np.abs(r["seq_encoder_output"][:, ::7, ::5].numpy() - g[tag + "_seq_encoder_output"]).max() < 1e-6
+    assert np.abs(r["latent"].numpy() - g[tag + "_latent"]).max() < 5e-6
+    assert np.abs(r["predicted_exp"].numpy() - g[tag + "_exp"]).max() < 1e-5
+    assert np.abs(r["predicted_jaw"].numpy() - g[tag + "_jaw"]).max() < 1e-5
+
+
+def test_emote_style_paths_match_reference():
+    """Per-frame external style, LinearEmotionCondition (only_style_emb) and the sample's own condition."""
+    g = _load("emote.npz")
+    w = W.make_emote_weights(1)
+    feat, style_t, expr, inten, ident, shape = emote_condition_inputs()
+    r = OE.forward(w, feat, style_t)
+    assert np.abs(r["predicted_exp"].numpy() - g["t_exp"]).max() < 1e-5
+    assert np.abs(r["predicted_jaw"].numpy() - g["t_jaw"]).max() < 1e-5
+    own = OE.style_condition(w, expr, inten, ident, shape)
+    assert np.abs(own.numpy() - g["own_style"]).max() < 1e-5
+    r = OE.forward(w, feat, own)
+    assert np.abs(r["predicted_exp"].numpy() - g["own_exp"]).max() < 1e-5
+    assert np.abs(r["predicted_jaw"].numpy() - g["own_jaw"]).max() < 1e-5
+
+
+def test_flint_decoder_matches_reference_l2ldecoder():
+    g = _load("emote.npz")
+    z = torch.randn(2, 5, 256, generator=torch.Generator().manual_seed(43))
+    out = OE.flint_decoder(W.make_emote_weights(1), z)
+    assert np.abs(out.numpy() - g["flint_z_out"]).max() < 5e-6
+
+
 def test_coeff_stats_fixture():
     """misc/coeff_{mean,std}.npy: float32 [53]; jaw std is tiny."""
     m, s = _load("coeff_mean.npy"), _load("coeff_std.npy")
