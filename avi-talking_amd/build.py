@@ -18,8 +18,15 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # instructions the same kernel is bit-exact (scripts/diag_concurrency.py: 100 % of runs wrong -> 0 %).  The sampling
 # pipeline overlaps a second stream with the audio branch, so every translation unit is built without them; the cost
 # is below the run-to-run noise of the step (AVI_PACKED_FP32=1 restores them for the diagnostic).
+# The mechanism inside the hardware is not established: tests/test_cabi_and_host.py disassembles the built
+# library and asserts that no such instruction is present, and lib.load() refuses a diagnostic build.
 if os.environ.get("AVI_PACKED_FP32", "0") != "1":
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+else:
+    FLAGS += ["-DAVI_BUILD_PACKED_FP32=1"]
+# the target feature is meaningless to the x86 host pass of hipcc, which says so once per translation unit
+HOST_PASS_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
 FLAGS += os.environ.get("AVI_DEFINES", "").split()      # e.g. -DAVI_PP_STAMPS for scripts/pp_stamps.py
 
 
@@ -52,9 +59,13 @@ def build(force=False, verbose=True):
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
+            procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
     for src, p in procs:
-        if p.wait() != 0:
+        err = p.communicate()[1]
+        err = "".join(l for l in err.splitlines(True) if HOST_PASS_NOISE not in l)
+        if err.strip():
+            sys.stderr.write(err)
+        if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     with open(stamp, "w") as fh:
         fh.write(flags)
@@ -66,5 +77,48 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def code_objects(lib=LIB):
+    """The gfx950 code objects (ELF images) embedded in the shared library: walks the clang offload bundles of its
+    .hip_fatbin section (magic, entry count, then (offset, size, triple) records)."""
+    import struct
+    data = open(lib, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return out
+        n = struct.unpack_from("<Q", data, i + len(magic))[0]
+        off = i + len(magic) + 8
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode(errors="replace")
+            off += tl
+            if "gfx950" in triple and sz:
+                out.append(data[i + o:i + o + sz])
+        pos = i + 1
+
+
+def instruction_census(lib=LIB, patterns=("v_mfma", r"v_pk_(fma|mul|add)_f32")):
+    """Counts of the instructions matching each regular expression over every gfx950 code object of the library
+    (llvm-objdump -d): {pattern: count}, plus the number of code objects under "code_objects"."""
+    import re
+    import tempfile
+    counts = {p: 0 for p in patterns}
+    objs = code_objects(lib)
+    for blob in objs:
+        with tempfile.NamedTemporaryFile(suffix=".elf") as fh:
+            fh.write(blob)
+            fh.flush()
+            asm = subprocess.run([OBJDUMP, "-d", fh.name], capture_output=True, text=True, check=True).stdout
+        for p in patterns:
+            counts[p] += len(re.findall(r"^\s*" + p, asm, flags=re.M))
+    counts["code_objects"] = len(objs)
+    return counts
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--census" in sys.argv:
+        print(instruction_census())

@@ -153,12 +153,8 @@ int launch_attention(const float* q, const float* k, const float* v, float* out,
     constexpr int RPW = D > 128 ? 4 : 8;  // D = 256: 16 query rows per workgroup keeps LDS under 160 KiB
     constexpr int QB = 4 * RPW;
     constexpr int smem = (KT * (D + 4) + KT * D + QB * D + 4 * KT) * (int)sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<D, RPW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(attention_kernel<D, RPW>), smem);
     dim3 grid((Tq + QB - 1) / QB, B * H);
     hipLaunchKernelGGL((attention_kernel<D, RPW>), grid, dim3(256), smem, s, q, k, v, out, H, Tq, Tk, ldq, ldk, ldo, scale,
                        bias_mode, slopes, period);

@@ -521,12 +521,8 @@ template <int D>
 int launch_fused(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk, int ldq,
                  int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period, hipStream_t s,
                  uint16_t* out_hi = nullptr, uint16_t* out_lo = nullptr) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM);
-        attr_done = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(attn_fused_kernel<D>), FUSED_SMEM);
     hipLaunchKernelGGL(attn_fused_kernel<D>, dim3((Tq + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, q, k, v, Tq, Tk,
                        H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo);
     return avi_launch_status();

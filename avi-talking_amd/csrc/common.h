@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/avi_talking.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -10,6 +11,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define AVI_WAVE 64
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one grant per (kernel, device),
+// taken lock-free on first use from any thread (a process that drives a second GPU, or first calls from two threads,
+// must not launch with more than 64 KB of dynamic LDS before the attribute is set on that device).  Two racing threads
+// both set the attribute (idempotent for a fixed size); kernels whose size varies request their maximum.
+struct AviLdsGrant {
+    static constexpr int MAX_DEV = 16;
+    std::atomic<int> bytes[MAX_DEV];
+    AviLdsGrant() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+    void ensure(const void* fn, int need) {
+        int dev = 0;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEV;
+        if (known && bytes[dev].load(std::memory_order_acquire) >= need) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, need);
+        if (!known) return;
+        int cur = bytes[dev].load(std::memory_order_relaxed);
+        while (cur < need && !bytes[dev].compare_exchange_weak(cur, need, std::memory_order_release)) {}
+    }
+};
 
 static inline int avi_launch_status() {
     hipError_t e = hipGetLastError();

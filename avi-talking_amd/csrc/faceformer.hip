@@ -182,12 +182,8 @@ extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float*
     if ((w->coeff_mean == nullptr) != (w->coeff_std == nullptr)) return AVI_EINVAL;
     const size_t smem = sizeof(float) * ((size_t)8 * w->D + 64 + NT + 8 + (size_t)NH * T);
     if (smem > 160 * 1024) return AVI_ENOSPC;
-    static size_t attr = 0;
-    if (smem > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(faceformer_decode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(faceformer_decode_kernel), 160 * 1024);
     hipLaunchKernelGGL(faceformer_decode_kernel, dim3(B), dim3(NT), smem, static_cast<hipStream_t>(stream), *w, cross,
                        B, T, kv_scratch, out);
     return avi_launch_status();

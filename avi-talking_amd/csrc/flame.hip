@@ -453,12 +453,8 @@ extern "C" int avi_flame_vertices(const AviFlameBasis* fbp, const float* shape, 
     }
     const int smem = K * 3 * VT * (int)sizeof(float);
     if (smem > 160 * 1024) return AVI_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flame_vertices_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(flame_vertices_kernel), 160 * 1024);
     hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, 0);
     hipLaunchKernelGGL(flame_vertices_kernel, dim3((fb.V + VT - 1) / VT, B), dim3(512), smem, s, fb, v_shaped, coef, xf,
                        T, verts);

@@ -220,12 +220,8 @@ template <int BN, int NS, int BMT>
 int launch_gemm_tile(const AviGemm& g, hipStream_t s) {
     const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + BN - 1) / BN;
     constexpr int smem = GemmSmem<BN, NS, BMT>::TOTAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BN, NS, BMT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_kernel<BN, NS, BMT>), smem);
     dim3 grid(tilesM * tilesN, g.batch, 1);
     hipLaunchKernelGGL((gemm_kernel<BN, NS, BMT>), grid, dim3(256), smem, s, g, tilesM, tilesN);
     return avi_launch_status();

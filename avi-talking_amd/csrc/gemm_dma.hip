@@ -242,12 +242,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_dma_kernel(const AviGemm g, cons
 template <int NS>
 int launch(const AviGemm& g, hipStream_t s) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<NS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        attr_done = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_dma_kernel<NS>), SMEM_BYTES);
     hipLaunchKernelGGL((gemm_dma_kernel<NS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();

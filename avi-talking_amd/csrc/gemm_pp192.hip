@@ -305,12 +305,8 @@ template <int NS, int NT>
 int launch(const AviGemm& g, hipStream_t s) {
     constexpr int BN = Geo<NT>::BN, SMEM_BYTES = Geo<NT>::SMEM_BYTES;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        attr_done = true;
-    }
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT>), SMEM_BYTES);
     hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();

@@ -332,14 +332,9 @@ int check_weights(const AviPriorWeights* w) {
 }
 
 void set_attr() {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prior_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prior_time_table_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-        done = true;
-    }
+    static AviLdsGrant grant_prior, grant_table;
+    grant_prior.ensure(reinterpret_cast<const void*>(prior_kernel), (int)sizeof(Smem));
+    grant_table.ensure(reinterpret_cast<const void*>(prior_time_table_kernel), (int)sizeof(Smem));
 }
 
 }  // namespace

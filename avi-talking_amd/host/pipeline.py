@@ -7,7 +7,10 @@ loop at :689-771) as one batched, graph-capturable pass:
     audio features + style --EMOTE head + FLINT decoder--> expression (B,T,50) | jaw (B,T,3)
 
 Differences from the reference loop that do not change results: utterances are batched (the
-reference runs batch 1), wav2vec2 runs once per utterance (the reference runs it twice,
+reference runs batch 1; audio statistics are therefore taken PER CLIP, which is what the HF processor inside
+AudioEncoders.py:170-178 computes when it only ever sees one utterance - ``joint_norm=True`` selects the processor's
+joint-over-the-batch quirk instead, under which a clip's coefficients depend on its batch mates and on how the batch
+is sharded over ranks; tests/test_gpu_fullsize.py pins batched == utterance by utterance), wav2vec2 runs once per utterance (the reference runs it twice,
 train_diffusion_prior.py:696 vs :764), no host syncs (NaN sweeps, .item()) and no per-step Python in
 the DDPM loop; the prior is sampled on a second HIP stream concurrently with the audio encoder.
 """
@@ -21,7 +24,7 @@ from .talking_head import TalkingHeadWrapper
 
 
 class SamplingPipeline:
-    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=True):
+    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False):
         self.device = torch.device(device)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
         self.prior = InstructDiffusionPrior.from_state_dict(prior_sd, device=device, prec=prec)

@@ -42,6 +42,93 @@ def bucketed_allreduce(flat, spans, group=None, async_op=True):
     return works
 
 
+class FlatLayout:
+    """Offsets of every parameter in the flat buffers: decay region first, every view 16-byte aligned.
+    Pure bookkeeping (no device memory), so the data-parallel span logic can be checked on the CPU."""
+
+    def __init__(self, shapes, order):
+        names = [n for n in order if n in shapes]
+        missing = [n for n in shapes if n not in names]
+        if missing:
+            raise ValueError(f"parameters without a slot in the flat layout: {missing[:4]}...")
+        dec = [n for n in names if not no_decay(n)]
+        nod = [n for n in names if no_decay(n)]
+        self.offset, self.shape = {}, {}
+        off = 0
+        for group in (dec, nod):
+            for n in group:
+                self.offset[n], self.shape[n] = off, tuple(shapes[n])
+                off += (math.prod(shapes[n]) + 3) // 4 * 4          # keep every view 16-byte aligned
+            if group is dec:
+                self.n_decay = off                        # [0, n_decay): weight decay; [n_decay, numel): none
+        self.numel = off
+        self.names = dec + nod
+
+    @classmethod
+    def of_state_dict(cls, state_dict, order):
+        return cls({n: tuple(t.shape) for n, t in state_dict.items()
+                    if t.is_floating_point() and not n.startswith("noise_scheduler")}, order)
+
+    def span(self, first, last):
+        """[start, end) of the contiguous run of parameters ``first`` .. ``last`` (padding included)."""
+        end = self.offset[last] + (math.prod(self.shape[last]) + 3) // 4 * 4
+        return (self.offset[first], end)
+
+
+def grad_spans(depth=6, n_blocks=4):
+    """(first, last) parameter names of the decay-region gradient spans in the order backward completes them
+    (``PriorTrainer.forward_backward`` calls ``GradSync.ready`` with exactly these, in this order); together with the
+    no-decay tail [n_decay, numel) they cover the flat gradient buffer exactly once
+    (tests/test_dist_gloo.py::test_grad_spans_cover_flat_buffer_once)."""
+    v, c = "voxel2clip.", "net.causal_transformer."
+    spans = [("net.to_time_embeds.0.1.net.0.0.weight", c + "project_out.weight"),      # the whole prior network
+             (v + "lin1.weight", v + "projector.8.weight")]
+    spans += [(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight") for b in reversed(range(n_blocks))]
+    spans.append((v + "lin0.0.weight", v + "lin0.1.weight"))
+    return spans
+
+
+class GradSync:
+    """Data-parallel gradient sum over the flat gradient buffer: one all-reduce per span, launched from inside backward
+    the moment a span is final (``ready``), the no-decay tail and the waits at the end (``finish``).  Device-agnostic:
+    "nccl" (= RCCL) on the GPU, "gloo" in the CPU tests.  Replaces the reference's dead ``distributed`` branches
+    (train_diffusion_prior.py:338,442,450)."""
+
+    def __init__(self, layout, depth=6, n_blocks=4, process_group=None):
+        self.layout, self.pg = layout, process_group
+        self.expected = [layout.span(a, b) for a, b in grad_spans(depth, n_blocks)]
+        self.works, self.done = [], []
+
+    def world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.pg)
+        return 1
+
+    def ready(self, G, first, last):
+        span = self.layout.span(first, last)
+        i = len(self.done)
+        if i >= len(self.expected) or span != self.expected[i]:
+            raise RuntimeError(f"gradient span {first}..{last} announced out of order (position {i})")
+        self.done.append(span)
+        if self.world() > 1:
+            self.works += bucketed_allreduce(G, [span], self.pg)
+
+    def finish(self, G):
+        """Reduce the no-decay tail, wait for every bucket; returns the world size (AdamW scales by 1/world)."""
+        if len(self.done) != len(self.expected):
+            raise RuntimeError(f"{len(self.expected) - len(self.done)} gradient spans were never announced")
+        self.done = []
+        world = self.world()
+        if world > 1:
+            L_ = self.layout
+            self.works += bucketed_allreduce(G, [(L_.n_decay, L_.numel)], self.pg)
+            for w in self.works:
+                w.wait()
+        self.works = []
+        return world
+
+
 class _Lin:
     """One Linear layer y = x W^T (+ b) with weights in the flat store."""
 
@@ -133,24 +220,10 @@ class ParamStore:
     """Flat fp32 parameter / gradient / Adam-moment buffers with named views; decay region first."""
 
     def __init__(self, state_dict, device, order):
-        names = [n for n in order if n in state_dict]
-        missing = [n for n in state_dict if n not in names and state_dict[n].is_floating_point()
-                   and not n.startswith("noise_scheduler")]
-        if missing:
-            raise ValueError(f"parameters without a slot in the flat layout: {missing[:4]}...")
-        dec = [n for n in names if not no_decay(n)]
-        nod = [n for n in names if no_decay(n)]
-        self.offset, self.shape = {}, {}
-        off = 0
-        for group in (dec, nod):
-            for n in group:
-                t = state_dict[n]
-                self.offset[n], self.shape[n] = off, tuple(t.shape)
-                off += (t.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
-            if group is dec:
-                self.n_decay = off                        # [0, n_decay): weight decay; [n_decay, numel): none
-        self.numel = off
-        self.names = dec + nod
+        self.layout = lay = FlatLayout.of_state_dict(state_dict, order)
+        self.offset, self.shape, self.n_decay, self.numel, self.names = (lay.offset, lay.shape, lay.n_decay, lay.numel,
+                                                                         lay.names)
+        off = lay.numel
         self.P = torch.zeros(off, dtype=torch.float32, device=device)
         for n in self.names:
             self.view(n).copy_(state_dict[n].to(device, torch.float32))
@@ -250,27 +323,16 @@ class PriorTrainer:
         k = torch.arange(4)[None, :]
         self.rel_index = dv(torch.clamp(q - k, min=0))                        # (3,4) bucket of each (i,j)
         self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
-        self._works = []
+        self.sync = GradSync(S.layout, depth, n_blocks, process_group)
         self._ttable = None
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
-    def _dp_world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size(self.pg)
-        return 1
-
-    def _span(self, first, last):
-        S = self.store
-        return (S.offset[first], S.offset[last] + math.prod(S.shape[last]))
-
     def _grads_ready(self, first, last):
         """Called as soon as the backward pass has finished writing the decay-region gradients from parameter
         ``first`` through ``last`` (contiguous in the flat buffer): start their all-reduce now, so it overlaps
         with the rest of backward (the 67 M-parameter aligner blocks dominate the 311 MB volume)."""
-        if self._dp_world() > 1:
-            self._works += bucketed_allreduce(self.store.G, [self._span(first, last)], self.pg)
+        self.sync.ready(self.store.G, first, last)
 
     # ------------------------------------------------------------------ helpers
     def refresh(self):
@@ -471,15 +533,7 @@ class PriorTrainer:
         """DP: finish the gradient sum over ranks (RCCL all-reduce over xGMI).  The weight buckets were launched
         from inside backward (``_grads_ready``); the small no-decay tail (biases, T5 table) goes last.  AdamW then
         scales by 1/world."""
-        world = self._dp_world()
-        if world == 1:
-            return 1
-        S = self.store
-        self._works += bucketed_allreduce(S.G, [(S.n_decay, S.numel)], self.pg)
-        for w in self._works:
-            w.wait()
-        self._works = []
-        return world
+        return self.sync.finish(self.store.G)
 
     def _set_dyn(self, lr):
         """Step-dependent AdamW scalars go through device memory so a captured graph can be replayed."""
@@ -525,6 +579,8 @@ class PriorTrainer:
             r = st["rand"]
             out = self.forward_backward(st["voxel"], st["target"], r["times"], r["noise"], temp, r["brain_keep"],
                                         r["image_keep"], r["dropout_masks"])
+            if self.allreduce_grads() != 1:
+                raise RuntimeError("capture_step is the single-GPU path: collectives stay outside the graph")
             self.optimizer_step(use_dyn=True, _in_graph=in_graph)
             return out
 

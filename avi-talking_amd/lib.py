@@ -146,6 +146,11 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.avi_version.restype = C.c_char_p
         lib.avi_version.argtypes = []
+        if b"packed-fp32" in lib.avi_version() and os.environ.get("AVI_ALLOW_PACKED_FP32", "0") != "1":
+            raise RuntimeError(
+                f"{LIB_PATH} is a diagnostic build WITH packed-FP32 instructions (AVI_PACKED_FP32=1): kernels using "
+                "them were corrupted by matrix-core kernels of a second stream (build.py).  Rebuild without it; "
+                "scripts/diag_concurrency.py sets AVI_ALLOW_PACKED_FP32=1 to load such a build on purpose.")
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args

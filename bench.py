@@ -10,8 +10,12 @@ configuration the reference object supports.  The whole pass 
 hipGraph and replayed per step.  Weights are seeded random-init of the reference architectures; data is
 synthetic band-limited noise.
 
-Multi-GPU (--gpus N under torch.distributed.run): utterances are independent, so each rank runs its own
-batch with no data-path collective (weak scaling); rank 0 reports units of all ranks / max-over-ranks time.
+Multi-GPU: utterances are independent, so each rank runs its own batch with no data-path collective (weak
+scaling); rank 0 reports units of all ranks / max-over-ranks time.  Ranks come from torch.distributed.run (the driver's
+command line: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when `--gpus N` is given without WORLD_SIZE,
+from this script itself: the parent spawns N children (one per GPU, 127.0.0.1 rendezvous) BEFORE any GPU call and
+exits with the worst child's code.  `--dry-run` runs the same launcher, rendezvous, barrier and max-over-ranks timing
+on the CPU over gloo with a stand-in step (tests/test_dist_gloo.py): no GPU, no HIP library.
 
 Prints ONE JSON line (see the round contract) with extra objects `roofline` (dominant kernel = the bf16
 MFMA GEMM, HIP-event timed live) and `cpu_baseline` (the CPU oracle on a bounded sample).
@@ -50,6 +54,87 @@ def synth_audio(B, N, seed):
     return x.clamp(-32768, 32767).to(torch.int16)
 
 
+def launch_ranks(n, argv, timeout):
+    """`python bench.py --gpus N` without a launcher: spawn N rank processes of this script.  The parent makes no GPU
+    call (a process that has initialised the GPU must not be replaced or forked), waits for all children, kills the
+    others by PID when one fails or the timeout expires, and returns the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    deadline = time.monotonic() + timeout
+    rc = 0
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is not None:
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+        if procs and (rc != 0 or time.monotonic() > deadline):
+            rc = rc or 124
+            for p in procs:
+                p.kill()
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args, world, rank):
+    """The N-rank scaffolding on the CPU (gloo): rendezvous, barrier, EXACTLY `steps` timed stand-in steps, max over
+    ranks, the gradient-span all-reduce of the training leg, one JSON line from rank 0.  The stand-in step is the CPU
+    oracle's EMOTE head on a tiny batch (the checker used as a placeholder workload; nothing here is a measurement)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.sharding import max_over_ranks
+    from avi_talking_amd.host.training import FlatLayout, GradSync, _layout, grad_spans
+    from oracle import emote as OE
+    torch.set_num_threads(1)
+    wh = W.make_emote_weights(1)
+    g = torch.Generator().manual_seed(1234 + rank)
+    feat, style = torch.randn(2, 16, 768, generator=g), torch.randn(2, 1, 128, generator=g)
+    step = lambda: OE.forward(wh, feat, style)
+    bar = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    for _ in range(args.warmup):
+        step()
+    bar()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    bar()
+    dt = max_over_ranks(time.perf_counter() - t0, torch.device("cpu"), dist if world > 1 else None)
+    # training leg: every gradient span announced in backward order and reduced once over the ranks
+    lay = FlatLayout.of_state_dict(W.make_prior_weights(3), _layout())
+    sync = GradSync(lay)
+    G = torch.full((lay.numel,), float(rank + 1))
+    for a, b in grad_spans():
+        sync.ready(G, a, b)
+    wsz = sync.finish(G)
+    ok = bool((G == sum(range(1, world + 1))).all()) and wsz == world
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (CPU/gloo stand-in, not a measurement)", "dry_run": True,
+                          "value": round(world * 2 * 16 * args.steps / dt, 1), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "scaling": "weak", "grad_spans_reduced_once": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,12 +148,22 @@ def main():
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--secondary-timeout", type=float, default=300.0,
                     help="seconds the roofline / cpu_baseline / flame / train legs may take before the line is printed "
-                         "without them")
+                         "without them (the process then exits with code 3)")
+    ap.add_argument("--joint-norm", action="store_true",
+                    help="audio statistics over the whole batch (the HF processor quirk of AudioEncoders.py:170-178) "
+                         "instead of per clip (what the reference's batch-1 loop computes; default)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the N-rank scaffolding (no GPU)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the spawned ranks may take")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing above or in this branch touches the GPU.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        raise SystemExit(dry_run(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -88,7 +183,7 @@ def main():
 
     prec = ops.PREC_BF16X3 if args.prec == "bf16x3" else ops.PREC_BF16
     wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
-    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=prec)
+    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=prec, joint_norm=args.joint_norm)
     pcm = synth_audio(B_CLIPS, N_SAMPLES, 1234 + rank).to(dev)
     voxel = torch.randn(B_CLIPS, 768, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
     noise = torch.randn(101, B_CLIPS, 1, 128, generator=torch.Generator().manual_seed(rank)).to(dev)
@@ -133,51 +228,51 @@ def main():
         "config": {"workload": "configs[1]: 32 clips x 10 s @16 kHz per GPU -> 250 frames @25 fps each; "
                                "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
                    "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
+                   "audio_normalisation": "joint over the batch" if args.joint_norm else "per clip",
                    "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
         "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-        "roofline": None, "cpu_baseline": None, "train": None, "flame": None, "clip_text": None,
+        "roofline": None, "cpu_baseline": None, "train": None, "faceformer": None, "flame": None, "clip_text": None,
     }
     printed = threading.Lock()
+    leg = {"name": "roofline"}
 
     def emit():
         if printed.acquire(blocking=False) and rank == 0:
             print(json.dumps(line), flush=True)
 
     def watchdog():
-        # a secondary measurement hung (the training leg is the only one with collectives): the sampling line,
-        # already measured, must still come out, and no rank may be left behind holding the GPU
-        if line["train"] is None:
-            line["train"] = {"error": f"secondary measurements exceeded {args.secondary_timeout} s"}
+        # a secondary measurement hung: the sampling line, already measured, still comes out, with the name of the leg
+        # that was running, and the process ends with a NON-ZERO code so that the hang is on record (no rank may be
+        # left behind holding the GPU; os._exit because a hung HIP call cannot be interrupted)
+        line["secondary_error"] = f"leg '{leg['name']}' exceeded --secondary-timeout {args.secondary_timeout} s"
         emit()
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
 
     timer = threading.Timer(args.secondary_timeout, watchdog)
     timer.daemon = True
     timer.start()
 
-    if rank == 0:
-        line["roofline"] = measure_gemm_roofline(pipe, pcm, voxel, noise, prec)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = measure_cpu_baseline(wa, wh, wp)
+    def run_leg(name, fn, only_rank0=True):
+        if only_rank0 and rank != 0:
+            return
+        leg["name"] = name
+        try:
+            line[name] = fn()
+        except Exception as e:  # the sampling line above must survive a failure of a secondary measurement
+            line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, prec, line["ms_per_step"]))
+    if world == 1 and not args.no_cpu_baseline:
+        run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
     del pipe
     torch.cuda.empty_cache()
-    if rank == 0 and not args.no_train:
-        try:
-            line["flame"] = measure_flame(dev)
-        except Exception as e:
-            line["flame"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-    if rank == 0 and not args.no_train:
-        try:
-            line["clip_text"] = measure_clip_text(dev)
-        except Exception as e:
-            line["clip_text"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_train:
-        try:
-            line["train"] = measure_train(wp, dev, world, rank, local_rank, dist, args)
-        except Exception as e:  # the sampling line above must survive a failure of the secondary measurement
-            line["train"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        run_leg("faceformer", lambda: measure_faceformer(dev))
+        run_leg("flame", lambda: measure_flame(dev))
+        run_leg("clip_text", lambda: measure_clip_text(dev))
+        run_leg("train", lambda: measure_train(wp, dev, world, rank, local_rank, dist, args), only_rank0=False)
     timer.cancel()
     emit()
     if dist is not None:
@@ -326,16 +421,22 @@ def gemm_family(kw):
     return f"gemm_kernel<64, {ns}, 128>"
 
 
-def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
-    """Per-launch HIP-event timing of the GEMM kernels on the stream each is launched on, over `reps` eager passes
-    of the same workload (the prior branch runs concurrently on its side stream, as in the timed region).
-    achieved = algorithmic FLOPs (2*M*N*K*batch per launch) / summed launch durations, per kernel family; the
-    `roofline` object describes the family with the most FLOPs per step (the dominant kernel), `others` the rest.  In bf16x3
-    mode each algorithmic FLOP costs three MFMA FLOPs, which `mfma_issued_frac` accounts for.  `traffic` = HBM
-    bytes per launch from the rocprofv3 PMC passes committed under profiles/ (scripts/pmc_traffic.py)."""
+def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
+    """Per-launch HIP-event timing, on the stream each kernel is launched on, of the kernels that make up the step:
+    every GEMM launch (launch stream) and the one-launch DDPM sampler (side stream, concurrent with the audio branch
+    as in the timed region), over `reps` eager passes of the same workload.
+      GEMM families: achieved = algorithmic FLOPs (2*M*N*K*batch per launch) / summed launch durations; in bf16x3 mode
+        each algorithmic FLOP costs three MFMA FLOPs (`mfma_issued_frac`).
+      Sampler: achieved = bytes of weight planes every workgroup streams through its CU (planes x DDPM steps x
+        workgroups; served by L2 / Infinity Cache, hence above the HBM-side `traffic`) / launch duration.
+    The `roofline` object is the family with the largest time per step (`frac_of_step` = its time / the measured step:
+    the sampler runs BESIDE the audio branch, so the shares of the two branches each approach 1), `others` the rest in
+    that order.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/."""
     from avi_talking_amd import ops
-    rec = []
+    rec, srec = [], []
     orig = ops.gemm_raw
+    prior = pipe.prior
+    orig_sample = prior.p_sample_loop
 
     def timed(**kw):
         s = torch.cuda.current_stream()
@@ -345,7 +446,17 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
         e1.record(s)
         rec.append((gemm_family(kw), e0, e1, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1)))
 
+    def timed_sample(*a, **kw):
+        s = torch.cuda.current_stream()              # the pipeline's side stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        out = orig_sample(*a, **kw)
+        e1.record(s)
+        srec.append((e0, e1))
+        return out
+
     ops.gemm_raw = timed
+    prior.p_sample_loop = timed_sample
     marks = []
     try:
         for _ in range(reps + 1):      # pass 0 lets the host run ahead of the device and is dropped
@@ -354,6 +465,7 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
         torch.cuda.synchronize()
     finally:
         ops.gemm_raw = orig
+        prior.p_sample_loop = orig_sample
     marks.append(len(rec))
     ns = 3 if prec == ops.PREC_BF16X3 else 1
     # every pass issues the same launches in the same order: a launch slot's duration is the MINIMUM over the kept
@@ -371,10 +483,14 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
         f[1] += fl * reps
         f[2] += reps
     traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("kernels", {})
+    tsrc = None
+    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("kernels", {})
+            tsrc = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            break
 
     def describe(name):
         ms, fl, n = fam[name]
@@ -389,44 +505,145 @@ def measure_gemm_roofline(pipe, pcm, voxel, noise, prec, reps=3):
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),
                 "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
-                "ms_per_step": round(ms / reps, 3), "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
+                "ms_per_step": round(ms / reps, 3), "frac_of_step": round(ms / reps / step_ms, 3),
+                "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
                 "traffic": t["hbm_bytes_per_launch"] if t else None}
 
-    # the dominant kernel is the family that carries the most algorithmic FLOPs of a step (a property of the workload,
-    # not of this run's timings)
-    order = sorted(fam, key=lambda k: -fam[k][1])
-    out = describe(order[0])
-    out["others"] = [describe(k) for k in order[1:]]
-    if traffic:
-        out["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    entries = [describe(k) for k in fam]
+    if srec:
+        B = voxel.shape[0]
+        sms = min(a.elapsed_time(b) for a, b in srec[1:])
+        spg = max(1, min(prior.samples_per_group, B))
+        groups = -(-B // spg)
+        cus = groups * getattr(prior, "cus_per_group", 1)
+        plane_bytes = sum(t.numel() * t.element_size() for t in prior.net._packs)
+        T = prior.noise_scheduler.num_timesteps
+        nbytes = plane_bytes * T * groups
+        t = next((v for k, v in traffic.items() if k.startswith("prior_sample")), None)
+        entries.append({
+            "bound": "hbm", "bound_detail": "weights re-streamed L2 -> CU every DDPM step (per-CU ingest, served by L2 / "
+                                            "Infinity Cache: neither the HBM nor the MFMA roof); latency-bound chain of "
+                                            f"{T} dependent steps",
+            "kernel": f"prior sampler ({T}-step DDPM in one launch, {groups} sample groups on {cus} CUs, side stream)",
+            "achieved": round(nbytes / sms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(nbytes / sms / 1e6 / 8000.0, 4), "per_cu_gbps": round(nbytes / cus / sms / 1e6, 1),
+            "launches_per_step": 1, "avg_launch_us": round(sms * 1e3, 1), "ms_per_step": round(sms, 3),
+            "frac_of_step": round(sms / step_ms, 3), "algorithmic_bytes_per_launch": nbytes,
+            "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
+            "traffic": t["hbm_bytes_per_launch"] if t else None})
+    entries.sort(key=lambda e: -e["ms_per_step"])
+    out = entries[0]
+    out["others"] = entries[1:]
+    if tsrc:
+        out["traffic_source"] = tsrc
     return out
 
 
-def measure_cpu_baseline(wa, wh, wp, clips=2, reps=2):
-    """The CPU oracle (fp32 torch restatement of the reference; a port, not the reference import, which cannot
-    travel to this box) on a bounded sample: `clips` x 10 s through the same path, 1 warm-up + `reps` timed."""
-    from oracle import emote as OE, prior as OP, wav2vec2 as OW
-    cores = torch.get_num_threads()
-    pcm = synth_audio(clips, N_SAMPLES, 99)
-    voxel = torch.randn(clips, 768, generator=torch.Generator().manual_seed(98))
-    noise = torch.randn(101, clips, 1, 128, generator=torch.Generator().manual_seed(97))
+def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16):
+    """the CPU oracle (fp32 torch restatement of the reference - a port; the reference import
+    cannot travel to this box) on a BOUNDED sample, units B1-B5 timed separately, 1 warm-up + `reps` timed repetitions,
+    median.  `value` = frames/s of the same path as the headline (B1 audio encoder + B3 prior + B2 head on one
+    10 s clip).  Threads: the GPU box gives one GPU's job a 16-core share (torch would otherwise start one thread per
+    visible core and oversubscribe it)."""
+    import statistics
+    from avi_talking_amd import weights as W
+    from oracle import emote as OE, faceformer as OF, prior as OP, wav2vec2 as OW
+    prev = torch.get_num_threads()
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    try:
+        pcm = synth_audio(1, N_SAMPLES, 99)
+        voxel = torch.randn(1, 768, generator=torch.Generator().manual_seed(98))
+        noise = torch.randn(101, 1, 1, 128, generator=torch.Generator().manual_seed(97))
+        st = {}
 
-    def one():
-        with torch.no_grad():
-            x = OW.normalize_audio(pcm, joint=True)
-            feat = OW.forward(wa, x, frame_num=T_FRAMES)
+        def med(fn, n=reps):
+            with torch.no_grad():
+                fn()
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+            return statistics.median(ts)
+
+        def b1():
+            st["feat"] = OW.forward(wa, OW.normalize_audio(pcm, joint=joint_norm), frame_num=T_FRAMES)
+
+        def b3():
             te, _ = OP.brain_network(wp, voxel)
-            style = OP.p_sample_loop(wp, te.view(clips, 1, 128), noise)
-            return OE.forward(wh, feat, style)
+            st["style"] = OP.p_sample_loop(wp, te.view(1, 1, 128), noise)
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        one()
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(clips * T_FRAMES / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{clips} clips x 10 s (same path, fp32 torch oracle, {reps} timed passes after 1 warm-up, "
-                      f"{dt:.2f} s per pass)"}
+        t1, t3 = med(b1), med(b3)
+        t2 = med(lambda: OE.forward(wh, st["feat"], st["style"]))
+        units = {"B1_wav2vec2_1x10s_s": round(t1, 4), "B2_emote_flint_head_1x250_s": round(t2, 4),
+                 "B3_aligner_plus_100step_ddpm_1_sample_s": round(t3, 4)}
+        # B4: FaceFormer AR loop, hidden (1,T,D), as written (whole prefix re-decoded every frame) and KV-cached
+        for D, T in ((64, 100), (1024, 100)):
+            wf = W.make_faceformer_weights(2, feature_dim=D)
+            hs = torch.randn(1, T, D, generator=torch.Generator().manual_seed(7))
+            units[f"B4_faceformer_D{D}_T{T}_as_written_frames_per_s"] = round(
+                T / med(lambda: OF.predict_as_written(wf, hs, 30), 3), 1)
+            units[f"B4_faceformer_D{D}_T{T}_cached_frames_per_s"] = round(T / med(lambda: OF.predict_cached(wf, hs, 30), 3), 1)
+        # B5: one training step (fwd + autograd bwd + AdamW over every parameter), B = 64
+        g = torch.Generator().manual_seed(5)
+        Bt = 64
+        params = {k: v.clone().requires_grad_(True) for k, v in wp.items()
+                  if v.is_floating_point() and not k.startswith("noise_scheduler")}
+        mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in params.items()}
+        vx, tg = torch.randn(Bt, 768, generator=g), torch.randn(Bt, 1, 128, generator=g) * 0.3
+        times, nz = torch.randint(0, 100, (Bt,), generator=g), torch.randn(Bt, 1, 128, generator=g)
+
+        def b5():
+            with torch.enable_grad():
+                loss = OP.train_loss(params, vx, tg, times, nz, 0.005)[0]
+                grads = torch.autograd.grad(loss, list(params.values()))
+            for (k, p_), g_ in zip(params.items(), grads):
+                OP.adamw_step(p_.data, g_, mom[k][0], mom[k][1], 1, 1e-4, weight_decay=0.0 if OP.no_decay(k) else 1e-2)
+
+        t5 = med(b5, 3)
+        units["B5_train_step_B64_s"] = round(t5, 4)
+        units["B5_train_samples_per_s"] = round(Bt / t5, 1)
+    finally:
+        torch.set_num_threads(prev)
+    total = t1 + t2 + t3
+    return {"value": round(T_FRAMES / total, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip x 10 s through the same path (B1 + B3 + B2 = {total:.2f} s), fp32 torch oracle, 1 warm-up + "
+                      f"{reps} timed repetitions each, median; audio normalised "
+                      + ("jointly" if joint_norm else "per clip"),
+            "units": units}
+
+
+def measure_faceformer(dev, reps=5):
+    """North_star's second decoder (row E, models/faceformer.py:710-729): the autoregressive FaceFormer decode, all T
+    frames in one launch, on hidden states resident in HBM.  T = 250 (10 s), D = 64 and 1024 (config/vocaset/demo.yaml),
+    one utterance and a batch of 32; best of `reps` event-timed calls."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.faceformer import Faceformer
+    out = {"workload": "FaceFormer AR decode, T = 250 frames per utterance, hidden states in HBM, period 30",
+           "cases": []}
+    for D in (64, 1024):
+        m = Faceformer(W.make_faceformer_weights(2, feature_dim=D), period=30, device=dev)
+        for B in (1, 32):
+            hs = torch.randn(B, T_FRAMES, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+            m.decode(hs)
+            torch.cuda.synchronize(dev)
+            evs = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                m.decode(hs)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize(dev)
+            ms = min(a.elapsed_time(b) for a, b in evs)
+            wbytes = (12 * D * D + 2 * 53 * D) * 4                       # fp32 weights touched per frame
+            out["cases"].append({"D": D, "utterances": B, "ms": round(ms, 3),
+                                 "frames_per_s": round(B * T_FRAMES / ms * 1e3, 1),
+                                 "us_per_frame_step": round(ms * 1e3 / T_FRAMES, 2),
+                                 "weight_bytes_per_step": wbytes,
+                                 "weight_stream_gbps_per_utterance": round(wbytes * T_FRAMES / ms / 1e6, 1)})
+    return out
 
 
 if __name__ == "__main__":

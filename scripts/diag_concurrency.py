@@ -21,6 +21,8 @@ serially is bit-exact.  What was ruled in and out (MI355X, ROCm 7.2):
     the victim's LDS / global traffic), which is why this script keeps using the library's own kernels.
 So the library is built without packed-FP32 instructions and this script prints zero differences.
   python scripts/diag_concurrency.py overlap | serial      (PRIO=0 for a normal-priority second stream)"""
+import os
+os.environ.setdefault("AVI_ALLOW_PACKED_FP32", "1")   # this tool loads a diagnostic build on purpose
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F

@@ -123,3 +123,45 @@ def test_partition_by_length():
         assert max(loads) - min(loads) <= max(lengths)
     assert partition_by_length([], 4) == [[], [], [], []]
     assert pad_to_multiple(250) == 256 and pad_to_multiple(256) == 256 and pad_to_multiple(1) == 8
+
+
+def test_library_has_no_packed_fp32_instructions(lib):
+    """build.py compiles every translation unit without v_pk_{fma,mul,add}_f32 (kernels using them were corrupted by
+    matrix-core kernels of a second stream; the mechanism is unknown, so the ban is enforced on the shipped binary
+    itself): disassemble every gfx950 code object of the library.  Matrix-core instructions must be there."""
+    spec = importlib.util.spec_from_file_location("avi_build", os.path.join(ROOT, "avi-talking_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    census = mod.instruction_census(lib.LIB_PATH)
+    assert census["code_objects"] >= 10
+    assert census["v_mfma"] > 2000
+    assert census[r"v_pk_(fma|mul|add)_f32"] == 0, census
+    assert "packed-fp32" not in lib.version()
+
+
+def test_loader_refuses_a_packed_fp32_diagnostic_build(lib, monkeypatch):
+    """lib.load() raises on a library whose version string marks an AVI_PACKED_FP32=1 build."""
+    import ctypes as C
+
+    class Fake:
+        def __init__(self, real):
+            self._real = real
+            self.avi_version = lambda: b"avi_talking_hip 0.2.0 (gfx950, packed-fp32 DIAGNOSTIC build)"
+            self.avi_version.restype = None
+            self.avi_version.argtypes = None
+
+        def __getattr__(self, k):
+            return getattr(self._real, k)
+
+    real = lib.load()
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(C, "CDLL", lambda path: Fake(real))
+    monkeypatch.delenv("AVI_ALLOW_PACKED_FP32", raising=False)
+    with pytest.raises(RuntimeError, match="packed-FP32"):
+        lib.load()
+    monkeypatch.setenv("AVI_ALLOW_PACKED_FP32", "1")
+    monkeypatch.setattr(lib, "_lib", None)
+    assert lib.load() is not None
+    monkeypatch.setattr(lib, "_lib", real)

@@ -88,3 +88,135 @@ def test_bucketed_gradient_allreduce():
     mp.spawn(_ar_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     expect = torch.arange(1000, dtype=torch.float32) * 3     # rank 0: x1, rank 1: x2
     assert torch.equal(ret["flat"], expect)
+
+
+# ----------------------------------------------------------------------------- training step: gradient spans
+def test_grad_spans_cover_flat_buffer_once():
+    """The spans PriorTrainer announces from inside backward (training.grad_spans, checked call by call by GradSync)
+    plus the no-decay tail cover [0, numel) of the shipped flat layout exactly once, without overlap."""
+    from avi_talking_amd.host.training import FlatLayout, _layout, grad_spans, no_decay
+    from avi_talking_amd.weights import make_prior_weights
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    spans = sorted(lay.span(a, b) for a, b in grad_spans()) + [(lay.n_decay, lay.numel)]
+    pos = 0
+    for a, b in spans:
+        assert a == pos and b > a, (a, b, pos)
+        pos = b
+    assert pos == lay.numel
+    # the decay region holds exactly the names the reference's substring rule decays (train_diffusion_prior.py:997-1003)
+    for n in lay.names:
+        assert (lay.offset[n] < lay.n_decay) == (not no_decay(n)), n
+    assert lay.numel >= sum(v.numel() for k, v in w.items() if v.is_floating_point() and not k.startswith("noise_scheduler"))
+
+
+def test_gradsync_rejects_unannounced_and_misordered_spans():
+    import pytest
+    from avi_talking_amd.host.training import FlatLayout, GradSync, _layout, grad_spans
+    from avi_talking_amd.weights import make_prior_weights
+    lay = FlatLayout.of_state_dict(make_prior_weights(3), _layout())
+    G = torch.zeros(lay.numel)
+    sync = GradSync(lay)
+    spans = grad_spans()
+    with pytest.raises(RuntimeError, match="out of order"):
+        sync.ready(G, *spans[1])
+    sync = GradSync(lay)
+    sync.ready(G, *spans[0])
+    with pytest.raises(RuntimeError, match="never announced"):
+        sync.finish(G)
+
+
+def _flat_grads(lay, w, half, seed=77, B=8):
+    """Oracle autograd gradients of the reference training loss (oracle/prior.py train_loss) on one half of a seeded
+    batch, packed into the trainer's flat layout."""
+    from oracle import prior as OP
+    g = torch.Generator().manual_seed(seed)
+    voxel, target = torch.randn(2 * B, 768, generator=g), torch.randn(2 * B, 1, 128, generator=g) * 0.3
+    times, noise = torch.randint(0, 100, (2 * B,), generator=g), torch.randn(2 * B, 1, 128, generator=g)
+    sl = slice(half * B, (half + 1) * B)
+    params = {k: v.clone().requires_grad_(True) for k, v in w.items() if k in lay.offset}
+    loss = OP.train_loss(params, voxel[sl], target[sl], times[sl], noise[sl], 0.005)[0]
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    G = torch.zeros(lay.numel)
+    for (k, p), gr in zip(params.items(), grads):
+        if gr is not None:
+            G[lay.offset[k]:lay.offset[k] + p.numel()] = gr.reshape(-1)
+    return G
+
+
+def _trainer_sync_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd.host.training import FlatLayout, GradSync, _layout, grad_spans
+    from avi_talking_amd.weights import make_prior_weights
+    torch.set_num_threads(2)
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    G = _flat_grads(lay, w, rank)
+    sync = GradSync(lay)
+    for a, b in grad_spans():               # the order PriorTrainer.forward_backward announces them in
+        sync.ready(G, a, b)
+    world_out = sync.finish(G)
+    G /= world_out                           # avi_adamw's 1/world gradient scale
+    if rank == 0:
+        ret["G"] = G.clone()
+        ret["world"] = world_out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_gradient_sync_world2_matches_single_process():
+    """World size 2 over gloo: each rank's oracle gradients on its half batch, reduced through the trainer's own span
+    bookkeeping (GradSync + the shipped layout), equal the single-process mean of the two half-batch gradients -
+    every element of the flat buffer (a span reduced twice or never would show)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    from avi_talking_amd.host.training import FlatLayout, _layout
+    from avi_talking_amd.weights import make_prior_weights
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    expect = (_flat_grads(lay, w, 0) + _flat_grads(lay, w, 1)) / 2
+    assert ret["world"] == 2
+    assert expect.abs().max() > 0
+    # the workers run 2 threads, this process more: fp32 summation order differs in the last bits
+    err = (ret["G"] - expect).abs().max().item()
+    print(f"max |sync - single process| = {err:.2e} (gradient scale {expect.abs().max().item():.2e})")
+    assert err < 2e-5 * expect.abs().max().item()
+
+
+# ----------------------------------------------------------------------------- bench.py launcher
+def test_bench_gpus_flag_spawns_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher in the environment starts 2 ranks itself (CPU/gloo rehearsal): one
+    JSON line from rank 0 with n_gpus = 2, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True and rec["grad_spans_reduced_once"] is True
+
+
+def test_bench_launcher_reports_failing_rank():
+    """A rank that dies makes the launcher kill the rest and exit non-zero (never a silent success)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r); sys.argv=['bench.py']; import bench; "
+            "bench.__file__ = os.path.join(%r, 'tests', '_failing_rank.py'); "
+            "sys.exit(bench.launch_ranks(2, [], 60))" % (root, root))
+    helper = os.path.join(root, "tests", "_failing_rank.py")
+    with open(helper, "w") as fh:
+        fh.write("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(120)\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    finally:
+        os.remove(helper)
+    assert r.returncode == 7, (r.returncode, r.stderr[-1000:])

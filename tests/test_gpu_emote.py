@@ -64,3 +64,40 @@ def test_style_condition_and_wrapper(gpu):
     own = th(dict(sample))                       # style from the sample's own conditions
     ref_own = OE.forward(wh, feat, ref_style)
     assert (own["predicted_exp"].cpu() - ref_own["predicted_exp"]).abs().max().item() < 1e-3
+
+
+def test_batched_pipeline_equals_oracle_utterance_by_utterance(gpu):
+    """SamplingPipeline's default (per-clip audio statistics) reproduces the reference's batch-1 loop
+    (train_diffusion_prior.py:689-771): a batched run equals the ORACLE run one utterance at a time, and a clip's
+    coefficients do not depend on its batch mates.  The processor's joint-over-the-batch mode is opt-in."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    from oracle import emote as OE, prior as OP, wav2vec2 as OW
+    wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
+    B, T = 3, 25
+    g = torch.Generator().manual_seed(77)
+    pcm = (torch.randn(B, T * 640, generator=g) * torch.tensor([500.0, 3000.0, 9000.0])[:, None]).to(torch.int16)
+    voxel = torch.randn(B, 768, generator=g)
+    noise = torch.randn(101, B, 1, 128, generator=g)
+    pipe = SamplingPipeline(wa, wh, wp, device=gpu)
+    assert pipe.talking_head.joint_norm is False
+    out = pipe.run(pcm.to(gpu), voxel.to(gpu), noise.to(gpu))
+    exp, jaw = out["predicted_exp"].cpu(), out["predicted_jaw"].cpu()
+    for b in range(B):
+        x = OW.normalize_audio(pcm[b:b + 1], joint=True)          # one utterance: joint == per clip
+        feat = OW.forward(wa, x, frame_num=T)
+        te, _ = OP.brain_network(wp, voxel[b:b + 1])
+        style = OP.p_sample_loop(wp, te.view(1, 1, 128), noise[:, b:b + 1])
+        ref = OE.forward(wh, feat, style)
+        e = max((exp[b] - ref["predicted_exp"][0]).abs().max().item(), (jaw[b] - ref["predicted_jaw"][0]).abs().max().item())
+        print(f"utterance {b}: batched HIP vs batch-1 oracle {e:.2e}")
+        assert e < 1e-3
+    # replace clips 0 and 2: clip 1's output must not move (it does under joint normalisation)
+    pcm2 = pcm.clone()
+    pcm2[0], pcm2[2] = pcm[2] // 3, pcm[0] * 2
+    out2 = pipe.run(pcm2.to(gpu), voxel.to(gpu), noise.to(gpu))
+    assert (out2["predicted_exp"].cpu()[1] - exp[1]).abs().max().item() < 1e-5
+    joint = SamplingPipeline(wa, wh, wp, device=gpu, joint_norm=True)
+    a = joint.run(pcm.to(gpu), voxel.to(gpu), noise.to(gpu))["predicted_exp"].cpu()[1]
+    b_ = joint.run(pcm2.to(gpu), voxel.to(gpu), noise.to(gpu))["predicted_exp"].cpu()[1]
+    assert (a - b_).abs().max().item() > 1e-4           # the documented coupling of the joint mode
