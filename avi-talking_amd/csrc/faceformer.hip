@@ -81,7 +81,7 @@ __device__ void add_layernorm(float* x, const float* r, long long rstride_unused
 }
 
 __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceformerWeights w,
-                                                                const float* __restrict__ cross, int B, int T,
+                                                                const float* __restrict__ cross, int B, int T, int chunk,
                                                                 float* __restrict__ kv, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = w.D, V = w.V, dh = D / NH;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
     float* o = h1 + 2 * D;      // [64]  coefficient frame (V <= 64)
     float* part = o + 64;       // [256]
     float* red = part + NT;     // [8]
-    float* sc = red + 8;        // [4][T] attention scores
+    float* sc = red + 8;        // [4][chunk] attention scores of the current chunk (chunk = T: the reference's window)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* kvb = kv + (long long)b * T * 2 * D;
@@ -110,12 +110,13 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
         for (int d = tid; d < 2 * D; d += NT) kvb[(long long)i * 2 * D + d] = q[D + d];
         __syncthreads();  // K/V of step i visible to the whole workgroup (same CU, workgroup scope)
 
-        // ---- self-attention over keys 0..i, head = wave
+        // ---- self-attention over keys ks..i (ks = start of the chunk frame i lies in), head = wave
         {
+            const int ks = (i / chunk) * chunk;
             const int hoff = wave * dh;
             const float scale = rsqrtf((float)dh);
             float mx = -1.0e30f;
-            for (int j = lane; j <= i; j += 64) {
+            for (int j = ks + lane; j <= i; j += 64) {
                 const float* kr = kvb + (long long)j * 2 * D + hoff;
                 float s = 0.f;
                 for (int d = 0; d < dh; d += 4) {
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
                     s = fmaf(q[hoff + d + 3], kk.w, s);
                 }
                 s = s * scale - slope * (float)((i - j) / w.period);
-                sc[wave * T + j] = s;
+                sc[wave * chunk + j - ks] = s;
                 mx = fmaxf(mx, s);
             }
             mx = wave_max(mx);
             float sum = 0.f;
-            for (int j = lane; j <= i; j += 64) {
-                const float p = __expf(sc[wave * T + j] - mx);
-                sc[wave * T + j] = p;
+            for (int j = ks + lane; j <= i; j += 64) {
+                const float p = __expf(sc[wave * chunk + j - ks] - mx);
+                sc[wave * chunk + j - ks] = p;
                 sum += p;
             }
             sum = wave_sum(sum);
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
             const int dd = lane % dl, jc = lane / dl;
             for (int d0 = 0; d0 < dh; d0 += 64) {
                 float a = 0.f;
-                for (int j = jc; j <= i; j += G)
-                    a = fmaf(sc[wave * T + j], kvb[(long long)j * 2 * D + D + hoff + d0 + dd], a);
+                for (int j = ks + jc; j <= i; j += G)
+                    a = fmaf(sc[wave * chunk + j - ks], kvb[(long long)j * 2 * D + D + hoff + d0 + dd], a);
                 for (int off = dl; off < 64; off <<= 1) a += __shfl_xor(a, off, 64);
                 if (jc == 0) att[hoff + d0 + dd] = a * inv;
             }
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
 
 }  // namespace
 
-extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
-                                     float* out, void* stream) {
+extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                                             float* kv_scratch, float* out, void* stream) {
     if (!w || !cross || !kv_scratch || !out || B <= 0 || T <= 0) return AVI_EINVAL;
     const int dh = w->D / NH;
     if (w->D < 16 || dh * NH != w->D || dh < 4 || (dh & (dh - 1)) != 0) return AVI_EINVAL;
@@ -180,11 +181,18 @@ extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float*
         !w->obj_embedding)
         return AVI_EINVAL;
     if ((w->coeff_mean == nullptr) != (w->coeff_std == nullptr)) return AVI_EINVAL;
-    const size_t smem = sizeof(float) * ((size_t)8 * w->D + 64 + NT + 8 + (size_t)NH * T);
+    if (chunk <= 0 || chunk > T) chunk = T;
+    if (chunk < T && chunk % w->period) return AVI_EINVAL;     // the PPE phase must run on across a chunk boundary
+    const size_t smem = sizeof(float) * ((size_t)8 * w->D + 64 + NT + 8 + (size_t)NH * chunk);
     if (smem > 160 * 1024) return AVI_ENOSPC;
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(faceformer_decode_kernel), 160 * 1024);
     hipLaunchKernelGGL(faceformer_decode_kernel, dim3(B), dim3(NT), smem, static_cast<hipStream_t>(stream), *w, cross,
-                       B, T, kv_scratch, out);
+                       B, T, chunk, kv_scratch, out);
     return avi_launch_status();
+}
+
+extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
+                                     float* out, void* stream) {
+    return avi_faceformer_decode_chunked(w, cross, B, T, T, kv_scratch, out, stream);
 }

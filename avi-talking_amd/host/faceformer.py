@@ -9,7 +9,13 @@ that have those embeddings pass them as ``cond_embeds=(eye (B,T,6), emo (B,T,30)
 ``audio_feature_map(wav2vec2(audio))`` as in upstream FaceFormer.
 
 Unlike the reference (batch forced to 1 by its 3-D mask, prefix re-decoded every step) the HIP path
-decodes B utterances at once with a KV cache, all T steps in one launch.
+decodes B utterances at once with a KV cache.  Two device paths behind ``decode``:
+  * narrow decoders (D < 256): all T steps in ONE launch, one workgroup per utterance (csrc/faceformer.hip);
+  * wide decoders (D >= 256, e.g. feature_dim 1024 of config/vocaset/demo.yaml): a chain of 6-7 small launches per
+    frame, each spread over the whole chip (csrc/faceformer_steps.hip), captured once per (B, T, chunk) in a hipGraph
+    and replayed.
+Long-form (T > 600, which the reference's tables do not reach: models/faceformer.py:88,147): ``decode(..., chunk=C)``
+selects the chunked-causal window defined in include/avi_talking.h (avi_faceformer_decode_chunked).
 """
 import ctypes as C
 import math
@@ -104,24 +110,123 @@ class Faceformer:
             cw.coeff_mean = dev(torch.as_tensor(coeff_mean, dtype=torch.float32).reshape(-1)[: self.V])
             cw.coeff_std = dev(torch.as_tensor(coeff_std, dtype=torch.float32).reshape(-1)[: self.V])
         self.cw = cw
+        import os
+        mode = os.environ.get("AVI_FF_STEPS", "auto")           # "0" / "1" force a path (tests), auto: by width
+        dh = D // NHEAD
+        can = D % 64 == 0 and D <= 1024 and dh in (16, 32, 64, 128, 256)
+        self.use_steps = can and (mode == "1" or (mode == "auto" and D >= 256))
+        self.planes = self._build_planes(w, p) if self.use_steps else None
+        self._graphs = {}
 
-    def decode(self, hidden_states):
-        """The autoregressive loop of ``predict`` (:710-729) for memory ``hidden_states`` (B,T,D)."""
+    def _build_planes(self, w, p):
+        """Derived constants of the launch-chain path (include/avi_talking.h AviFaceformerPlanes): fragment-major bf16
+        hi/lo planes of the four streamed matrices and the fused input map of a frame's q/k/v:
+        qkv_i = in_proj(vertice_map(o_{i-1}) + pe_i) = (W_in W_map) o_{i-1} + [W_in (b_map + pe_i) + b_in]
+        (the products are formed in fp64 and rounded once to fp32)."""
+        D, V, dvc = self.D, self.V, self.device
+
+        def frag(mat):                                       # [N][K] fp32 -> hi, lo [N/16][K/32][4][16][8]
+            pw = ops.PackedWeight(mat.to(dvc).contiguous())
+            N, K = pw.hi.shape
+            f = lambda t: t.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+            hi, lo = f(pw.hi), f(pw.lo)
+            self._keep += [hi, lo]
+            return hi.data_ptr(), lo.data_ptr()
+
+        def keep(t):
+            t = t.to(torch.float32).to(dvc).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        pl = L.AviFaceformerPlanes()
+        wm_pad = torch.zeros(D, 64)
+        wm_pad[:, :V] = w["vertice_map.weight"]
+        # [out_proj | vertice_map]: s1 = self-attention + input embedding comes out of ONE accumulation over [att | o]
+        pl.wo_hi, pl.wo_lo = frag(torch.cat([w[p + "self_attn.out_proj.weight"], wm_pad], 1))
+        pl.w1_hi, pl.w1_lo = frag(w[p + "linear1.weight"])
+        pl.w2_hi, pl.w2_lo = frag(w[p + "linear2.weight"])
+        pl.wr_hi, pl.wr_lo = frag(w["vertice_map_r.weight"])                    # N = V -> padded to 64 rows of zeros
+        Win, b_in = w[p + "self_attn.in_proj_weight"].double(), w[p + "self_attn.in_proj_bias"].double()
+        Wm, bm = w["vertice_map.weight"].double(), w["vertice_map.bias"].double()   # (D, V), (D)
+        pe = ppe_period(D, self.period).double()
+        wf_t = torch.zeros(64, 3 * D, dtype=torch.float64)
+        wf_t[:V] = (Win @ Wm).t()
+        pl.wf_t = keep(wf_t)
+        pl.bf = keep((bm[None] + pe) @ Win.t() + b_in[None])                     # (period, 3D)
+        x0 = w["obj_embedding"].reshape(-1).double() + pe[0]
+        pl.qkv0 = keep(Win @ x0 + b_in)
+        pl.x0 = keep(x0)
+        return pl
+
+    def _chunk(self, T, chunk):
+        if chunk is None:
+            if T > self.max_seq_len:
+                raise ValueError(f"T={T} exceeds the reference's mask/PPE length {self.max_seq_len}: pass chunk= to "
+                                 "select the chunked-causal window (include/avi_talking.h)")
+            return T
+        chunk = int(chunk)
+        if chunk <= 0 or (chunk < T and chunk % self.period):
+            raise ValueError("chunk must be a positive multiple of the PPE period")
+        return min(chunk, T)
+
+    def decode(self, hidden_states, chunk=None):
+        """The autoregressive loop of ``predict`` (:710-729) for memory ``hidden_states`` (B,T,D).  ``chunk``: attention
+        window for long-form decoding (None = the reference's full causal window, T <= 600)."""
         hs = hidden_states.to(self.device, torch.float32).contiguous()
         B, T, D = hs.shape
         if D != self.D:
             raise ValueError(f"hidden_states has D={D}, decoder has D={self.D}")
-        if T > self.max_seq_len:
-            raise ValueError(f"T={T} exceeds the reference's mask/PPE length {self.max_seq_len}")
+        chunk = self._chunk(T, chunk)
         cross = ops.linear(ops.linear(hs, self.cross_v, prec=self.prec), self.cross_o, prec=self.prec)
+        if self.use_steps:
+            return self._decode_steps(cross, B, T, chunk)
         kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
         out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
-        L.check(L.load().avi_faceformer_decode(C.byref(self.cw), cross.data_ptr(), B, T, kv.data_ptr(),
-                                               out.data_ptr(), L.stream_ptr()), "avi_faceformer_decode")
+        L.check(L.load().avi_faceformer_decode_chunked(C.byref(self.cw), cross.data_ptr(), B, T, chunk, kv.data_ptr(),
+                                                       out.data_ptr(), L.stream_ptr()), "avi_faceformer_decode_chunked")
+        return out
+
+    def _decode_steps(self, cross, B, T, chunk, rows_per_call=32):
+        """Wide decoders: the per-frame launch chain, one hipGraph per (rows, T, chunk) over static buffers, replayed
+        for every block of up to 32 utterances."""
+        out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
+        so = L.load()
+        for b0 in range(0, B, rows_per_call):
+            nb = min(rows_per_call, B - b0)
+            key = (nb, T, chunk)
+            g = self._graphs.get(key)
+            if g is None:
+                n = C.c_longlong()
+                L.check(so.avi_faceformer_steps_work_floats(self.D, nb, C.byref(n)), "work size")
+                st = dict(cross=torch.empty((nb, T, self.D), dtype=torch.float32, device=self.device),
+                          kv=torch.empty((nb, T, 2 * self.D), dtype=torch.float32, device=self.device),
+                          work=torch.zeros(n.value, dtype=torch.float32, device=self.device),
+                          out=torch.empty((nb, T, self.V), dtype=torch.float32, device=self.device))
+
+                def chain():
+                    L.check(so.avi_faceformer_decode_steps(C.byref(self.cw), C.byref(self.planes), st["cross"].data_ptr(),
+                                                           nb, T, chunk, st["kv"].data_ptr(), st["work"].data_ptr(),
+                                                           st["out"].data_ptr(), L.stream_ptr()),
+                            "avi_faceformer_decode_steps")
+                if torch.cuda.is_current_stream_capturing():   # already inside a caller's graph: just enqueue
+                    st["cross"].copy_(cross[b0:b0 + nb])
+                    chain()
+                    out[b0:b0 + nb] = st["out"]
+                    continue
+                st["cross"].copy_(cross[b0:b0 + nb])
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    chain()
+                g = self._graphs[key] = (graph, st)
+            graph, st = g
+            st["cross"].copy_(cross[b0:b0 + nb])
+            graph.replay()
+            out[b0:b0 + nb] = st["out"]
         return out
 
     @torch.no_grad()
-    def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None):
+    def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None, chunk=None):
         if self.audio_encoder is None:
             raise RuntimeError("Faceformer was built without audio encoder weights")
         feats = self.audio_encoder(audio.to(self.device), "vocaset").last_hidden_state     # :673
@@ -139,4 +244,4 @@ class Faceformer:
             if o != self.merge_in:
                 raise ValueError("cond_embeds do not match v_merge2hidden's input width")
             hs = ops.linear(cat, self.v_merge2hidden, prec=self.prec)                      # :708
-        return self.decode(hs)
+        return self.decode(hs, chunk=chunk)

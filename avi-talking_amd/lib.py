@@ -81,6 +81,11 @@ class AviFaceformerWeights(C.Structure):
                                     "coeff_mean", "coeff_std")])
 
 
+class AviFaceformerPlanes(C.Structure):
+    _fields_ = [(n, _vp) for n in ("wo_hi", "wo_lo", "w1_hi", "w1_lo", "w2_hi", "w2_lo", "wr_hi", "wr_lo", "wf_t", "bf",
+                                   "qkv0", "x0")]
+
+
 # name -> argtypes; every function returns int status.  Kept in one table so the CPU-side test can
 # check that the library exports every symbol the header declares.
 SIGNATURES = {
@@ -113,6 +118,9 @@ SIGNATURES = {
     "avi_prior_sample_batched_tab": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "avi_prior_time_table": [_vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "avi_faceformer_decode_chunked": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "avi_faceformer_steps_work_floats": [_i, _i, C.POINTER(_ll)],
+    "avi_faceformer_decode_steps": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_transpose": [_vp, _i, _i, _vp, _vp],

@@ -280,6 +280,39 @@ typedef struct AviFaceformerWeights {
  * step i read memory row i only); kv_scratch >= B*T*2*D floats; out [B][T][V]. One launch for all T steps. */
 int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
                           float* out, void* stream);
+/* Long-form decode (BASELINE.json configs[4], T up to tens of thousands).  The reference cannot decode more than 600
+ * frames: its ALiBi mask and PPE table stop there (models/faceformer.py:88,147) and `predict` fails on the slice.
+ * CHUNKED-CAUSAL semantics defined here: frame i attends to frames floor(i/chunk)*chunk .. i only (the KV cache restarts
+ * at every multiple of `chunk`), the ALiBi distance is i-j as before, the PPE phase is i mod period (chunk must be a
+ * multiple of period, so the phase runs on across the boundary), and the input embedding of the first frame of a
+ * chunk is vertice_map(previous output) as for every other frame - motion stays continuous, only the attention window
+ * is cut.  chunk >= T (or chunk = 0) is exactly the reference's predict(); oracle: oracle/faceformer.py
+ * predict_cached(chunk=...). */
+int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                                  float* kv_scratch, float* out, void* stream);
+
+/* The same decode for WIDE decoders (D >= 256; config/vocaset/demo.yaml uses feature_dim 1024) as a chain of small
+ * launches per frame, every one spread over the whole chip, instead of one workgroup per utterance streaming all
+ * 8 D^2 weights through one CU per frame: self-attention as split-key partials over the KV cache, the four Linear
+ * layers as 16-column slices on the matrix cores (bf16 3-term split of fragment-major weight planes), LayerNorms in
+ * between.  The caller captures the whole chain (6-7 launches x T) in one hipGraph and replays it.
+ * Derived constants, built once per model by the host (avi-talking_amd/host/faceformer.py): */
+typedef struct AviFaceformerPlanes {
+    const uint16_t *wo_hi, *wo_lo;   /* [self_attn.out_proj | vertice_map.weight (V columns padded to 64)]: [D][D + 64] as bf16
+                                        hi/lo planes in fragment-major order [N/16][K/32][64 lanes][8] */
+    const uint16_t *w1_hi, *w1_lo;   /* linear1 [2D][D] */
+    const uint16_t *w2_hi, *w2_lo;   /* linear2 [D][2D] */
+    const uint16_t *wr_hi, *wr_lo;   /* vertice_map_r [64 (V padded with zero rows)][D] */
+    const float* wf_t;               /* [64][3D]: (in_proj . vertice_map)^T, rows >= V zero: qkv of frame i from frame i-1 */
+    const float* bf;                 /* [period][3D]: in_proj (vertice_map.bias + pe[p]) + in_proj.bias */
+    const float* qkv0;               /* [3D]: in_proj (obj_embedding + pe[0]) + in_proj.bias (frame 0) */
+    const float* x0;                 /* [D]:  obj_embedding + pe[0] */
+} AviFaceformerPlanes;
+/* *floats = size of `work` (in floats) the chain needs for B utterances of width D */
+int avi_faceformer_steps_work_floats(int D, int B, long long* floats);
+/* Enqueues the whole chain on `stream`.  D a multiple of 64 with D/4 in {16,...,256}; B <= 32 per call. */
+int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
+                                int B, int T, int chunk, float* kv_scratch, float* work, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training step (aligner + prior; train_diffusion_prior.py:434-499).  Backward GEMMs reuse avi_gemm:

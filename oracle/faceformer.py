@@ -77,9 +77,15 @@ def predict_as_written(w, hidden_states, period, coeff_mean=None, coeff_std=None
     return out
 
 
-def predict_cached(w, hidden_states, period, coeff_mean=None, coeff_std=None):
+def predict_cached(w, hidden_states, period, coeff_mean=None, coeff_std=None, chunk=None):
     """Same function, O(T) decoder work: self-attention K/V appended per step; cross-attention reduces
-    to out_proj(v_proj(memory[i])) because row i of the memory mask opens column i only."""
+    to out_proj(v_proj(memory[i])) because row i of the memory mask opens column i only.
+
+    ``chunk`` (a multiple of ``period``; None = the reference's full causal window) is the long-form extension the
+    reference does NOT have (its mask and PPE tables stop at 600 frames, models/faceformer.py:88,147, and predict()
+    fails beyond them): frame i attends to frames floor(i/chunk)*chunk .. i only; ALiBi distance (i-j)//period,
+    PPE phase i % period and the fed-back embedding vertice_map(previous output) are unchanged.  PARITY UNPINNED for
+    chunk < T (there is no reference behaviour to pin it to); chunk >= T is pinned by tests/golden/faceformer_*.npz."""
     B, T, D = hidden_states.shape
     dh = D // NHEAD
     pe = ppe_table(D, period)[0]
@@ -95,14 +101,16 @@ def predict_cached(w, hidden_states, period, coeff_mean=None, coeff_std=None):
     emb = w["obj_embedding"].expand(B, D)
     outs = []
     for i in range(T):
-        x = emb + pe[i]
+        x = emb + pe[i % period]             # the table is periodic (rows beyond 600 + period do not exist in it)
         qkv = F.linear(x, Wi, bi)
         q, Kc[:, i], Vc[:, i] = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         qh = q.view(B, NHEAD, 1, dh)
-        kh = Kc[:, :i + 1].view(B, i + 1, NHEAD, dh).transpose(1, 2)
-        vh = Vc[:, :i + 1].view(B, i + 1, NHEAD, dh).transpose(1, 2)
+        k0 = 0 if not chunk else (i // chunk) * chunk
+        n = i + 1 - k0
+        kh = Kc[:, k0:i + 1].view(B, n, NHEAD, dh).transpose(1, 2)
+        vh = Vc[:, k0:i + 1].view(B, n, NHEAD, dh).transpose(1, 2)
         s = torch.matmul(qh, kh.transpose(2, 3)) * dh ** -0.5
-        dist = (i - torch.arange(i + 1)) // period
+        dist = (i - torch.arange(k0, i + 1)) // period
         s = s - slopes[None, :, None, None] * dist[None, None, None, :].float()
         a = torch.matmul(torch.softmax(s, -1), vh).reshape(B, D)
         x = _ln(w, p + ".norm1", x + F.linear(a, w[p + ".self_attn.out_proj.weight"], w[p + ".self_attn.out_proj.bias"]))

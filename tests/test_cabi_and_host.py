@@ -39,6 +39,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.AviPriorLayer) == 8 * 8
     assert C.sizeof(lib.AviPriorWeights) == 8 + 13 * 8 + 8 * 64 + 5 * 8
     assert C.sizeof(lib.AviFaceformerWeights) == 16 + 23 * 8
+    assert C.sizeof(lib.AviFaceformerPlanes) == 12 * 8
     assert C.sizeof(lib.AviFlameBasis) == 7 * 8 + 3 * 4 + 4 + 2 * 8     # + basis_hi, basis_lo (after padding)
     assert C.sizeof(lib.AviTransposeJob) == 4 * 8 + 4 * 4 + 8           # in, out, hi, lo | R, C, C_pad, first_block | colsum
 

@@ -27,17 +27,41 @@ def test_decode_matches_reference_golden(gpu, D):
     assert err < 1e-3 and err_n < 1e-3
 
 
-@pytest.mark.parametrize("B,T,D,period", [(3, 100, 64, 25), (2, 40, 128, 30), (1, 300, 64, 30)])
-def test_decode_batched_vs_oracle(gpu, B, T, D, period):
+@pytest.mark.parametrize("steps", ["0", "1"])
+@pytest.mark.parametrize("B,T,D,period", [(3, 100, 64, 25), (2, 40, 128, 30), (1, 300, 64, 30), (33, 20, 256, 30)])
+def test_decode_batched_vs_oracle(gpu, monkeypatch, steps, B, T, D, period):
+    """Both device paths (one workgroup per utterance / the per-frame launch chain) against the cached oracle."""
     from avi_talking_amd.weights import make_faceformer_weights
     from avi_talking_amd.host.faceformer import Faceformer
     from oracle import faceformer as OF
+    monkeypatch.setenv("AVI_FF_STEPS", steps)
     w = make_faceformer_weights(2, feature_dim=D)
     hs = torch.randn(B, T, D, generator=torch.Generator().manual_seed(51))
     ref = OF.predict_cached(w, hs, period)
-    out = Faceformer(w, period=period, device=gpu).decode(hs.to(gpu)).cpu()
+    ff = Faceformer(w, period=period, device=gpu)
+    assert ff.use_steps == (steps == "1")
+    out = ff.decode(hs.to(gpu)).cpu()
     err = (out - ref).abs().max().item()
-    print(f"B={B} T={T} D={D}: err {err:.2e} scale {ref.std():.2f}")
+    print(f"steps={steps} B={B} T={T} D={D}: err {err:.2e} scale {ref.std():.2f}")
+    assert err < 1e-3
+    if steps == "1":                      # second call replays the cached graph on new inputs
+        hs2 = torch.randn(B, T, D, generator=torch.Generator().manual_seed(52))
+        err2 = (ff.decode(hs2.to(gpu)).cpu() - OF.predict_cached(w, hs2, period)).abs().max().item()
+        assert err2 < 1e-3
+
+
+def test_wide_decoder_uses_the_launch_chain_and_splits_keys(gpu):
+    """D = 1024 (config/vocaset/demo.yaml): auto-selected launch chain; T = 200 makes the attention split its keys
+    (more than 48 KB of K/V per head from frame 24 on) and merge the partials."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF
+    w = make_faceformer_weights(2, feature_dim=1024)
+    hs = torch.randn(2, 200, 1024, generator=torch.Generator().manual_seed(53))
+    ff = Faceformer(w, period=30, device=gpu)
+    assert ff.use_steps
+    err = (ff.decode(hs.to(gpu)).cpu() - OF.predict_cached(w, hs, 30)).abs().max().item()
+    print(f"D=1024 T=200 launch chain: err {err:.2e}")
     assert err < 1e-3
 
 

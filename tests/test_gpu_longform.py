@@ -29,8 +29,34 @@ def test_60s_utterance_matches_oracle(gpu):
 
 
 def test_faceformer_rejects_sequences_beyond_reference_tables(gpu):
+    """Without an explicit chunk the reference's limit stands (its predict() fails beyond 600 frames)."""
     from avi_talking_amd.weights import make_faceformer_weights
     from avi_talking_amd.host.faceformer import Faceformer
     ff = Faceformer(make_faceformer_weights(2, feature_dim=64), device=gpu)
     with pytest.raises(ValueError):
         ff.decode(torch.zeros(1, 601, 64, device=gpu))
+    with pytest.raises(ValueError):
+        ff.decode(torch.zeros(1, 700, 64, device=gpu), chunk=100)        # not a multiple of the period (30)
+
+
+@pytest.mark.parametrize("steps,D", [("0", 64), ("1", 64), ("1", 256)])
+def test_faceformer_chunked_causal_60s(gpu, monkeypatch, steps, D):
+    """BASELINE config 5: T = 1500 frames through the FaceFormer decoder with the chunked-causal window
+    (include/avi_talking.h avi_faceformer_decode_chunked; chunk = 600 = the reference's table length) against the
+    oracle's definition of the same window, on both device paths."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF
+    monkeypatch.setenv("AVI_FF_STEPS", steps)
+    T = 1500
+    w = make_faceformer_weights(2, feature_dim=D)
+    hs = torch.randn(2, T, D, generator=torch.Generator().manual_seed(71))
+    ref = OF.predict_cached(w, hs, 30, chunk=600)
+    ff = Faceformer(w, period=30, device=gpu)
+    out = ff.decode(hs.to(gpu), chunk=600).cpu()
+    err = (out - ref).abs().max().item()
+    print(f"steps={steps} D={D} T=1500 chunk=600: err {err:.2e}")
+    assert out.shape == (2, T, 53) and err < 1e-3
+    # the first chunk is the reference's own decode of the first 600 frames
+    ref600 = OF.predict_cached(w, hs[:, :600], 30)
+    assert (out[:, :600] - ref600).abs().max().item() < 1e-3

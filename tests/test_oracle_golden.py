@@ -136,6 +136,25 @@ def test_flint_decoder_matches_reference_l2ldecoder():
     assert np.abs(out.numpy() - g["flint_z_out"]).max() < 5e-6
 
 
+def test_faceformer_chunked_window_definition():
+    """The long-form extension (oracle/faceformer.py predict_cached(chunk=...)): a window that covers the sequence is
+    the reference's decode; a shorter window leaves the first chunk untouched and changes later frames only through
+    the attention window (the fed-back embedding keeps the motion continuous across the boundary)."""
+    w = W.make_faceformer_weights(2, feature_dim=64)
+    hs = torch.randn(1, 75, 64, generator=torch.Generator().manual_seed(9))
+    full = OF.predict_cached(w, hs, 15)
+    assert torch.equal(OF.predict_cached(w, hs, 15, chunk=75), full)
+    assert torch.equal(OF.predict_cached(w, hs, 15, chunk=90), full)
+    ch = OF.predict_cached(w, hs, 15, chunk=30)
+    assert torch.equal(ch[:, :30], full[:, :30])
+    assert not torch.equal(ch[:, 30:], full[:, 30:])
+    # frame 30 sees only itself: its self-attention output is its own value vector, whatever came before
+    hs2 = hs.clone()
+    hs2[:, :29] += 1.0                       # changes frames 0..28 only; frame 29's output o_29 feeds frame 30
+    ch2 = OF.predict_cached(w, hs2, 15, chunk=30)
+    assert not torch.equal(ch2[:, :29], ch[:, :29])
+
+
 def test_coeff_stats_fixture():
     """misc/coeff_{mean,std}.npy: float32 [53]; jaw std is tiny."""
     m, s = _load("coeff_mean.npy"), _load("coeff_std.npy")
