@@ -284,10 +284,15 @@ class InstructDiffusionPrior:
         return self._time_table
 
     def draw_noise(self, batch, generator=None):
-        """The (T+1, B, 1, 128) noise sequence the reference draws call by call from
-        ``torch.randn(..., generator=generator)`` (models/diffusion_prior.py:337,349-351)."""
+        """The (T+1, B, 1, 128) noise sequence, drawn CALL BY CALL in the reference's order and shapes: first the
+        initial embedding ``torch.randn(shape, generator=generator)`` (models/diffusion_prior.py:347-351), then one
+        ``torch.randn(x.size(), generator=generator)`` per DDPM step from t = T-1 down to 0 (:337; the reference also
+        draws - and then masks - the one at t = 0).  T+1 separate draws of (B,1,128), so that the same generator state
+        gives the same numbers as the reference loop on the same device type (one (T+1,B,1,128) draw does not: the
+        Philox offsets of one large call differ from those of T+1 small ones)."""
         T = self.noise_scheduler.num_timesteps
-        return torch.randn((T + 1, batch, 1, DIM), device=self.device, generator=generator)
+        draws = [torch.randn((batch, 1, DIM), device=self.device, generator=generator) for _ in range(T + 1)]
+        return torch.stack(draws, 0)
 
     @torch.no_grad()
     def p_sample_loop(self, shape, text_cond, cond_scale=1.0, timesteps=None, generator=None, image_embed=None,

@@ -16,3 +16,11 @@ for spg in (0, 1, 2, 3, 4, 5):
     for _ in range(10): pipe.replay()
     torch.cuda.synchronize()
     print(f"samples_per_group={spg}: {(time.time()-t)/10*1e3:.2f} ms per pass", flush=True)
+# the sampler alone (no audio branch beside it), per samples_per_group
+te = torch.randn(B, 1, 128, device=dev)
+for spg in (1, 2, 3, 4, 5):
+    f = lambda: pipe.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": te}, noise=noise, samples_per_group=spg)
+    f(); torch.cuda.synchronize(); t = time.time()
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    print(f"sampler alone, samples_per_group={spg}: {(time.time()-t)/5*1e3:.2f} ms", flush=True)

@@ -1,0 +1,127 @@
+"""CPU: host-side helpers around the hot path - audio framing (row A0), lr / temperature schedules (row C6), the
+command-line surface and the noise draw order of the sampler."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# name -> (type, default) of every flag at train_diffusion_prior.py:909-947 (data copied from the reference's parser)
+REFERENCE_FLAGS = {
+    "max_epoch": (int, 5000), "epoch": (int, 0), "local_rank": (int, 0), "clip_size": (int, 128),
+    "model_name": (str, "EMOTE"), "use_projector": (bool, True), "jobname": (str, "text2emo"), "save_subdir": (str, ""),
+    "is_tensorboard_log": (int, 1), "is_test": (int, 0), "is_talking_instruct": (int, 0), "log_loss_steps": (int, 5),
+    "resume_from_ckpt": (int, 0), "ckpt_path": (str, ""), "test_json_path": (str, ""), "is_output_gt": (int, 0),
+    "is_use_rvd": (int, 0), "is_cal_diversity": (int, 0), "is_vis_diversity": (int, 0), "is_no_diffusion": (int, 0),
+    "unset_prior": (int, 0), "unset_v2c": (int, 0), "load_talkclip_dataset": (int, 1), "wo_dataset_aug": (int, 0),
+    "dataset_names": (str, ""), "seq_length": (int, 25), "vertice_dim": (int, 53), "batch_size": (int, 1),
+    "workers": (int, 8), "only_load_caption": (int, 1), "max_lr": (float, 3e-4),
+}
+
+
+def test_cli_has_every_reference_flag_with_its_default():
+    from avi_talking_amd.host.cli import build_parser
+    args = build_parser().parse_args([])
+    for name, (typ, default) in REFERENCE_FLAGS.items():
+        assert hasattr(args, name), name
+        assert getattr(args, name) == default and isinstance(getattr(args, name), typ), name
+    assert args.test_audio_path.endswith("W019_front_angry_level2_007.wav") and hasattr(args, "path_to_models")
+    # the argument list experiments/diffusion_test.sh passes
+    a = build_parser().parse_args(
+        "--dataset_names Mead_M,Mead_W --jobname align_emote_x --vertice_dim 15069 --batch_size 256 --resume_from_ckpt 1 "
+        "--ckpt_path train_logs/a/last.pth --only_load_caption 1 --is_tensorboard_log 0 --max_lr 0.001 "
+        "--test_audio_path a.wav --test_json_path caps/ --is_test 1 --is_talking_instruct 1 --is_output_gt 0 "
+        "--save_subdir res --is_no_diffusion 0 --is_cal_diversity 0 --is_vis_diversity 0 --is_use_rvd 0".split())
+    assert a.is_test == 1 and a.max_lr == 0.001 and a.batch_size == 256 and a.vertice_dim == 15069
+    assert build_parser().parse_args(["--no-use_projector"]).use_projector is False
+
+
+def test_cli_output_folder_layout():
+    from avi_talking_amd.host.cli import output_folder
+    f = output_folder("/runs/emote", "res", "/data/Mead_W/W019_front_angry_level2_007/W019_front_angry_level2_007.wav")
+    assert f == "/runs/emote/test_videos_res/Mead_W/W019_front_angry_level2_007"
+
+
+def _write_wav(path, x, rate=16000, nch=1):
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(nch)
+        f.setsampwidth(2)
+        f.setframerate(rate)
+        f.writeframes(x.astype("<i2").tobytes())
+
+
+def test_read_and_process_audio(tmp_path):
+    """evaluation_functions.py:680-714: int16 mono, cut at 22 s, whole (T, 640) frames."""
+    from avi_talking_amd.host.audio_io import process_audio, read_audio
+    rng = np.random.default_rng(0)
+    x = rng.integers(-20000, 20000, 16000 * 23 + 123).astype(np.int16)
+    _write_wav(tmp_path / "a.wav", x)
+    wav, sr = read_audio(tmp_path / "a.wav")
+    assert sr == 16000 and wav.dtype == np.int16 and wav.shape[0] == 22 * 16000
+    assert np.array_equal(wav, x[:22 * 16000])
+    s = process_audio(wav, sr, 25)
+    assert s["samplerate"] == 16000 and s["raw_audio"].shape == (550, 640)
+    assert np.array_equal(s["raw_audio"].reshape(-1), x[:550 * 640])
+    short = process_audio(x[:1000], 16000, 25)                      # 1 whole frame, remainder dropped
+    assert short["raw_audio"].shape == (1, 640) and np.array_equal(short["raw_audio"][0], x[:640])
+    assert process_audio(x[:100], 16000, 25)["raw_audio"].shape == (0, 640)
+    st = np.stack([x[:3200], -x[:3200]], 1).reshape(-1)             # stereo -> mono mean = 0
+    _write_wav(tmp_path / "st.wav", st, nch=2)
+    assert np.abs(read_audio(tmp_path / "st.wav")[0]).max() == 0
+    _write_wav(tmp_path / "r.wav", x[:100], rate=44100)
+    with pytest.raises(ValueError):
+        read_audio(tmp_path / "r.wav")
+    with pytest.raises(AssertionError):
+        process_audio(x[:100], 16000, 30)
+
+
+def test_fixture_wav_through_the_helpers():
+    """The reference's fixture clip (tests/golden/fixture_wav_ch0.npz, 79 872 samples) -> 124 frames of 640."""
+    from avi_talking_amd.host.audio_io import process_audio
+    pcm = np.load(os.path.join(ROOT, "tests", "golden", "fixture_wav_ch0.npz"))["pcm"]
+    s = process_audio(pcm, 16000, 25)
+    assert s["raw_audio"].shape == (79872 // 640, 640) and s["raw_audio"].dtype == np.int16
+
+
+@pytest.mark.parametrize("epochs,n", [(10, 7), (40, 3), (5, 11)])
+def test_one_cycle_lr_matches_torch(epochs, n):
+    """train_diffusion_prior.py:343-357: OneCycleLR(max_lr, epochs*len*5, final_div_factor 1000, pct_start 2/epochs)."""
+    from avi_talking_amd.host.schedule import reference_schedule
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    total = int(epochs * n) * 5
+    ref = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total, final_div_factor=1000, last_epoch=-1,
+                                              pct_start=2 / epochs)
+    mine = reference_schedule(1e-3, epochs, n)
+    for s in range(total - 1):
+        assert abs(opt.param_groups[0]["lr"] - mine.lr_at(s)) <= 1e-12 + 1e-9 * mine.lr_at(s)
+        assert abs(mine.get_last_lr()[0] - mine.lr_at(s)) == 0
+        opt.step()
+        ref.step()
+        mine.step()
+
+
+def test_cosine_anneal_matches_oracle():
+    from avi_talking_amd.host.schedule import cosine_anneal
+    from oracle import prior as OP
+    a = torch.tensor(cosine_anneal(0.004, 0.0075, 37), dtype=torch.float64)
+    assert torch.allclose(a.float(), OP.cosine_anneal(0.004, 0.0075, 37), atol=1e-9)
+
+
+def test_draw_noise_call_order_matches_reference_loop():
+    """T+1 separate (B,1,128) draws from the generator: x_T first, then one per step (models/diffusion_prior.py:337,
+    347-351) - checked on the CPU generator against the reference's call sequence."""
+    from types import SimpleNamespace
+    from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior
+    obj = InstructDiffusionPrior.__new__(InstructDiffusionPrior)
+    obj.device = torch.device("cpu")
+    obj.noise_scheduler = SimpleNamespace(num_timesteps=100)
+    out = InstructDiffusionPrior.draw_noise(obj, 3, torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(0)
+    ref = [torch.randn((3, 1, 128), generator=g)]                 # image_embed = torch.randn(shape, generator)
+    for _ in range(100):
+        ref.append(torch.randn(torch.Size((3, 1, 128)), dtype=torch.float32, generator=g))   # p_sample noise
+    assert out.shape == (101, 3, 1, 128) and torch.equal(out, torch.stack(ref))
