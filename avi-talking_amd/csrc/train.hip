@@ -692,6 +692,45 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// ------------------------------------------------------------------ data movement of the step (no torch kernels inside
+// the captured training step: see tests/test_gpu_library_only.py)
+__global__ void zero_kernel(float4* __restrict__ p, long long n4, float* __restrict__ tail, int ntail) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+
+// dst[r][0..C) = src[(idx ? idx[r] : r)][0..C) with row strides in elements (gather of table rows / strided row copy)
+__global__ void copy_rows_kernel(const float* __restrict__ src, long long src_stride, const int* __restrict__ idx,
+                                 float* __restrict__ dst, long long dst_stride, int rows, int C) {
+    const long long total = (long long)rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (long long)r * C);
+        dst[r * dst_stride + c] = src[(idx ? idx[r] : r) * src_stride + c];
+    }
+}
+
+// T5 relative-position bias of the 3-token denoiser (dalle2 RelPosBias called with (n, n+1), models/diffusion_prior.py:159):
+// bucket of max(i - j, 0) is the distance itself below 16, so bias[h][i][j] = emb[max(i - j, 0)][h]; backward scatters.
+__global__ void rel_bias_kernel(const float* __restrict__ emb, float* __restrict__ bias, const float* __restrict__ dbias,
+                                float* __restrict__ demb, int heads, int n) {
+    const int t = threadIdx.x;
+    if (bias) {
+        if (t < heads * n * (n + 1)) {
+            const int h = t / (n * (n + 1)), r = t - h * n * (n + 1), i = r / (n + 1), j = r - i * (n + 1);
+            const int d = i - j > 0 ? i - j : 0;
+            bias[t] = emb[d * heads + h];
+        }
+    } else if (t < heads * n) {       // one thread per (bucket d, head): fixed summation order
+        const int d = t / heads, h = t - d * heads;
+        float a = 0.f;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= n; ++j)
+                if ((i - j > 0 ? i - j : 0) == d) a += dbias[(h * n + i) * (n + 1) + j];
+        demb[d * heads + h] += a;
+    }
+}
+
 }  // namespace
 
 #define S_(x) static_cast<hipStream_t>(x)
@@ -857,5 +896,27 @@ extern "C" int avi_adamw(float* p, const float* g, float* m, float* v, long long
     const float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2, 256, 4096)), dim3(256), 0, S_(stream), p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), grad_scale, dyn, hi, lo);
+    return avi_launch_status();
+}
+
+extern "C" int avi_zero(float* p, long long n, void* stream) {
+    if (!p || n <= 0 || (reinterpret_cast<uintptr_t>(p) & 15)) return AVI_EINVAL;
+    const long long n4 = n >> 2;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, S_(stream),
+                       reinterpret_cast<float4*>(p), n4, p + 4 * n4, (int)(n & 3));
+    return avi_launch_status();
+}
+extern "C" int avi_copy_rows(const float* src, long long src_stride, const int* row_index, float* dst,
+                             long long dst_stride, int rows, int C, void* stream) {
+    if (!src || !dst || rows <= 0 || C <= 0) return AVI_EINVAL;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long long)rows * C)), dim3(256), 0, S_(stream), src, src_stride,
+                       row_index, dst, dst_stride, rows, C);
+    return avi_launch_status();
+}
+extern "C" int avi_prior_rel_bias(const float* emb, float* bias, const float* dbias, float* demb, int heads, int n,
+                                  void* stream) {
+    if (!((emb && bias && !dbias && !demb) || (!emb && !bias && dbias && demb))) return AVI_EINVAL;
+    if (heads <= 0 || n <= 0 || heads * n * (n + 1) > 256) return AVI_EINVAL;
+    hipLaunchKernelGGL(rel_bias_kernel, dim3(1), dim3(256), 0, S_(stream), emb, bias, dbias, demb, heads, n);
     return avi_launch_status();
 }

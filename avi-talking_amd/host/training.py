@@ -401,7 +401,7 @@ class PriorTrainer:
         x = voxel.to(dev, torch.float32).contiguous()
         target = clip_target.reshape(B, DIM).to(dev, torch.float32).contiguous()
         dm = dropout_masks or [None] * (self.n_blocks + 1)
-        S.G.zero_()
+        L.check(so.avi_zero(S.G.data_ptr(), S.numel, st()), "zero")
 
         # ---- BrainNetwork forward (models/diffusion_prior.py:95-117, train mode)
         h0p = self.lin0.fwd(x)
@@ -419,8 +419,9 @@ class PriorTrainer:
         proj = self.proj[2].fwd(z2)
 
         # ---- prior forward (p_losses, models/diffusion_prior.py:369-400)
-        t32 = times.to(dev, torch.int32).contiguous()
-        te0 = self.time_table.index_select(0, t32.long())
+        t32 = times if (times.dtype == torch.int32 and times.device == dev) else times.to(dev, torch.int32)
+        te0 = torch.empty((B, DIM), dtype=torch.float32, device=dev)
+        L.check(so.avi_copy_rows(self.time_table.data_ptr(), DIM, t32.data_ptr(), te0.data_ptr(), DIM, B, DIM, st()), "temb")
         a1p = self.tm[0].fwd(te0)
         a1 = torch.empty_like(a1p)
         L.check(so.avi_act_fwd(a1p.data_ptr(), a1p.numel(), ops.ACT_SILU, a1.data_ptr(), st()), "act")
@@ -438,7 +439,9 @@ class PriorTrainer:
                                         L.ptr(bk), L.ptr(ik), S.ptr("net.null_brain_embeds"),
                                         S.ptr("net.null_image_embed"), S.ptr("net.learned_query"), B, x0.data_ptr(),
                                         tok.data_ptr(), st()), "tokens_fwd")
-        rel_bias = S.view(self.c + "rel_pos_bias.relative_attention_bias.weight")[self.rel_index].permute(2, 0, 1).contiguous()
+        rel_name = self.c + "rel_pos_bias.relative_attention_bias.weight"
+        rel_bias = torch.empty((8, 3, 4), dtype=torch.float32, device=dev)
+        L.check(so.avi_prior_rel_bias(S.ptr(rel_name), rel_bias.data_ptr(), None, None, 8, 3, st()), "rel_bias")
         saved = []
         for ly in self.layers:
             a, f = ly["a"], ly["f"]
@@ -460,10 +463,13 @@ class PriorTrainer:
             tok = tok_next
         fin = self._ln(tok, self.c + "norm.g", stable=1)
         po = self.cproj.fwd(fin)
-        pred = po.view(B, 3, DIM)[:, 2].contiguous()
+        pred = torch.empty((B, DIM), dtype=torch.float32, device=dev)                 # tokens[:, -1] (:311)
+        L.check(so.avi_copy_rows(po.data_ptr() + 2 * DIM * 4, 3 * DIM, None, pred.data_ptr(), DIM, B, DIM, st()), "pred")
 
         # ---- losses (+ their gradients)
-        losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        zbuf = torch.empty(4 + R * DIM + 96, dtype=torch.float32, device=dev)         # losses | d(project_out) | d(rel bias)
+        L.check(so.avi_zero(zbuf.data_ptr(), zbuf.numel(), st()), "zero")
+        losses = zbuf[0:2]
         dpred = torch.empty_like(pred)
         L.check(so.avi_mse_loss(pred.data_ptr(), x0.data_ptr(), B * DIM, self.prior_mult, losses.data_ptr(),
                                 dpred.data_ptr(), st()), "mse")
@@ -473,11 +479,11 @@ class PriorTrainer:
                                       losses.data_ptr() + 4, dproj.data_ptr(), scratch.data_ptr(), st()), "clip")
 
         # ---- prior backward
-        dpo = torch.zeros((B, 3, DIM), dtype=torch.float32, device=dev)
-        dpo[:, 2] = dpred
+        dpo = zbuf[4:4 + R * DIM].view(B, 3, DIM)
+        L.check(so.avi_copy_rows(dpred.data_ptr(), DIM, None, dpo.data_ptr() + 2 * DIM * 4, 3 * DIM, B, DIM, st()), "dpo")
         dfin = self.cproj.bwd(fin, dpo.view(R, DIM))
         dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1)
-        drel = torch.zeros((8, 3, 4), dtype=torch.float32, device=dev)
+        drel = zbuf[4 + R * DIM:4 + R * DIM + 96].view(8, 3, 4)
         for ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(self.layers), reversed(saved)):
             a, f = ly["a"], ly["f"]
             dsw = ly["w2"].bwd(sw, dtok)
@@ -494,8 +500,7 @@ class PriorTrainer:
             dn1 = ly["qkv"].bwd(n1, dqkv)
             dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm)
         # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
-        gemb = S.grad(self.c + "rel_pos_bias.relative_attention_bias.weight")
-        gemb.index_put_((self.rel_index.reshape(-1),), drel.permute(1, 2, 0).reshape(12, 8), accumulate=True)
+        L.check(so.avi_prior_rel_bias(None, None, drel.data_ptr(), S.gptr(rel_name), 8, 3, st()), "rel_bias_bwd")
         dtext = torch.empty((B, DIM), dtype=torch.float32, device=dev)
         dtemb = torch.empty((B, DIM), dtype=torch.float32, device=dev)
         L.check(so.avi_prior_tokens_bwd(dtok.data_ptr(), L.ptr(bk), L.ptr(ik), B, dtext.data_ptr(), dtemb.data_ptr(),

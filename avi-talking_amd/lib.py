@@ -123,6 +123,9 @@ SIGNATURES = {
     "avi_faceformer_decode_steps": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "avi_zero": [_vp, _ll, _vp],
+    "avi_copy_rows": [_vp, _ll, _vp, _vp, _ll, _i, _i, _vp],
+    "avi_prior_rel_bias": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "avi_transpose": [_vp, _i, _i, _vp, _vp],
     "avi_transpose_jobs": [_vp, _i, _vp],
     "avi_transpose_table": [_vp, _i, _i, _vp],

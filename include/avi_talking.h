@@ -328,6 +328,17 @@ int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const
 int avi_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mask,
                       int rows, int C, float eps, int act, int stable, const float* dx_add, float* dx, float* dgamma,
                       float* dbeta, int accumulate, float* stats, void* stream);   /* dx = dLN/dx + dx_add (or NULL) */
+/* Data movement of the step, so that a captured training step contains library kernels only
+ * (tests/test_gpu_library_only.py): p[0..n) = 0 (p 16-byte aligned) */
+int avi_zero(float* p, long long n, void* stream);
+/* dst[r][0..C) = src[row_index ? row_index[r] : r][0..C), row strides in elements: the time-embedding lookup
+ * (models/diffusion_prior.py:284), pred = tokens[:, -1] (:311) and its gradient scatter */
+int avi_copy_rows(const float* src, long long src_stride, const int* row_index, float* dst, long long dst_stride,
+                  int rows, int C, void* stream);
+/* T5 relative-position bias of the n-token denoiser (dalle2 RelPosBias(n, n+1), models/diffusion_prior.py:159):
+ * forward (emb [32][heads] -> bias [heads][n][n+1], dbias = demb = NULL) or backward (demb += scatter of dbias,
+ * emb = bias = NULL); distances below 16 are their own bucket, so n <= 16 */
+int avi_prior_rel_bias(const float* emb, float* bias, const float* dbias, float* demb, int heads, int n, void* stream);
 /* [R][C] -> [C][R] */
 int avi_transpose(const float* in, int R, int C, float* out, void* stream);
 /* hi/lo [C_pad][R] = bf16 hi/lo split of in^T (in is [R][Cc] fp32; rows Cc..C_pad-1 are zero): the transposed
