@@ -274,7 +274,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                                                          int ldk, float scale_in, int bias_mode,
                                                          const float* __restrict__ slopes, int period,
                                                          float* __restrict__ out, int ldo,
-                                                         uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo) {
+                                                         uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo,
+                                                         int out_fmt) {
     constexpr int KS = D >= 32 ? D / 32 : 1;      // k-steps of the score product
     constexpr int DT = D / 16;                    // 16-dim tiles of the output
     constexpr int CH = D / 8;                     // 16-B chunks (8 dims) per image row
@@ -505,10 +506,11 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                     uint32_t hh[2], ll[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
-                        const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
-                        hh[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-                        ll[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                        uint16_t h0, h1, l0, l1;
+                        avi_split_hl(v[2 * j], out_fmt, h0, l0);
+                        avi_split_hl(v[2 * j + 1], out_fmt, h1, l1);
+                        hh[j] = h0 | ((uint32_t)h1 << 16);
+                        ll[j] = l0 | ((uint32_t)l1 << 16);
                     }
                     *reinterpret_cast<uint2*>(out_hi + o + dt * 16) = make_uint2(hh[0], hh[1]);
                     *reinterpret_cast<uint2*>(out_lo + o + dt * 16) = make_uint2(ll[0], ll[1]);
@@ -520,11 +522,11 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
 template <int D>
 int launch_fused(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int Tk, int ldq,
                  int ldk, int ldo, float scale, int bias_mode, const float* slopes, int period, hipStream_t s,
-                 uint16_t* out_hi = nullptr, uint16_t* out_lo = nullptr) {
+                 uint16_t* out_hi = nullptr, uint16_t* out_lo = nullptr, int out_fmt = AVI_PLANES_BF16) {
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(attn_fused_kernel<D>), FUSED_SMEM);
     hipLaunchKernelGGL(attn_fused_kernel<D>, dim3((Tq + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, q, k, v, Tq, Tk,
-                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo);
+                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo, out_fmt);
     return avi_launch_status();
 }
 
@@ -567,26 +569,29 @@ int avi_attention_fused_launch(const float* q, const float* k, const float* v, f
 // Head-dim-64 attention over a packed QKV projection whose result is written as split bf16 planes (and optionally as
 // fp32 too): the operand format of the ping-pong GEMM that consumes it (the encoder's out_proj).
 extern "C" int avi_attention_d64_planes(const float* qkv, int B, int H, int T, int ld, float scale, float* out,
-                                        uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+                                        uint16_t* out_hi, uint16_t* out_lo, int ldo, int plane_fmt, void* stream) {
     if (!qkv || !out_hi || !out_lo || B <= 0 || H <= 0 || T <= 0 || (ld & 3) || (ldo & 3)) return AVI_EINVAL;
+    if (plane_fmt != AVI_PLANES_BF16 && plane_fmt != AVI_PLANES_F16) return AVI_EINVAL;
     if (ld < 3 * H * HD || ldo < H * HD || (long long)B * H > 65535) return AVI_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
         ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 7))
         return AVI_EINVAL;
     return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, 0, nullptr, 1,
-                            static_cast<hipStream_t>(stream), out_hi, out_lo);
+                            static_cast<hipStream_t>(stream), out_hi, out_lo, plane_fmt);
 }
 
 // The same with the bias modes of avi_attention (2 with zero slopes = the plain causal mask of the CLIP text model).
 extern "C" int avi_attention_d64_planes_biased(const float* qkv, int B, int H, int T, int ld, float scale,
                                                int bias_mode, const float* slopes, int period, float* out,
-                                               uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream) {
+                                               uint16_t* out_hi, uint16_t* out_lo, int ldo, int plane_fmt,
+                                               void* stream) {
     if (!qkv || !out_hi || !out_lo || B <= 0 || H <= 0 || T <= 0 || (ld & 3) || (ldo & 3)) return AVI_EINVAL;
+    if (plane_fmt != AVI_PLANES_BF16 && plane_fmt != AVI_PLANES_F16) return AVI_EINVAL;
     if (ld < 3 * H * HD || ldo < H * HD || (long long)B * H > 65535) return AVI_EINVAL;
     if (bias_mode < 0 || bias_mode > 2 || (bias_mode != 0 && !slopes) || period < 1) return AVI_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
         ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 7))
         return AVI_EINVAL;
     return launch_fused<64>(qkv, qkv + H * HD, qkv + 2 * H * HD, out, B, H, T, T, ld, ld, ldo, scale, bias_mode, slopes,
-                            period, static_cast<hipStream_t>(stream), out_hi, out_lo);
+                            period, static_cast<hipStream_t>(stream), out_hi, out_lo, plane_fmt);
 }

@@ -57,6 +57,20 @@ __device__ __forceinline__ float avi_erf(float x) {
     return x * a * __builtin_amdgcn_rcpf(b);
 }
 
+// Split-plane activation formats (x = hi + lo): two bf16 (AVI_PLANES_BF16, operands of the 3-term bf16 GEMM) or two fp16
+// (AVI_PLANES_F16, operands of the opt-in 2-term fp16 GEMM AVI_PREC_F16X2).  Returns the 16-bit patterns.
+__device__ __forceinline__ void avi_split_hl(float v, int fmt, uint16_t& h, uint16_t& l) {
+    if (fmt == AVI_PLANES_F16) {
+        const _Float16 hh = (_Float16)v;
+        h = __builtin_bit_cast(uint16_t, hh);
+        l = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)hh));
+    } else {
+        const __bf16 hb = (__bf16)v;
+        h = __builtin_bit_cast(uint16_t, hb);
+        l = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)hb));
+    }
+}
+
 __device__ __forceinline__ float avi_gelu(float x) {
     // exact-form GELU: 0.5 x (1 + erf(x / sqrt(2)))  (torch.nn.functional.gelu, approximate='none'); |error| < 1e-6
     return 0.5f * x * (1.0f + avi_erf(x * 0.70710678118654752440f));

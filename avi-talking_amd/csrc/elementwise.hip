@@ -5,15 +5,10 @@
 namespace {
 
 // split-plane helpers: x = hi + lo (two bf16), 4 values at a time
-__device__ __forceinline__ void split4_store(uint16_t* hi, uint16_t* lo, long long o, const float v[4]) {
+__device__ __forceinline__ void split4_store(uint16_t* hi, uint16_t* lo, long long o, const float v[4], int fmt) {
     uint16_t h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 hb = (__bf16)v[j];
-        const __bf16 lb = (__bf16)(v[j] - (float)hb);
-        h[j] = __builtin_bit_cast(uint16_t, hb);
-        l[j] = __builtin_bit_cast(uint16_t, lb);
-    }
+    for (int j = 0; j < 4; ++j) avi_split_hl(v[j], fmt, h[j], l[j]);
     *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
     *reinterpret_cast<uint2*>(lo + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
 }
@@ -154,7 +149,8 @@ constexpr int C0_TT = 64;
 __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ x, int N, int T0,
                                                            const float* __restrict__ w0,
                                                            const float* __restrict__ ss, float* __restrict__ y,
-                                                           uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo) {
+                                                           uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo,
+                                                           int fmt) {
     __shared__ float sx[C0_TT * ST0 + K0 + 2];
     const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
     const float* xb = x + (long long)b * N;
@@ -191,7 +187,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         }
         const long long off = ((long long)b * T0 + t) * C0 + cg * 4;
         if (y) *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
-        if (y_hi) split4_store(y_hi, y_lo, off, o);
+        if (y_hi) split4_store(y_hi, y_lo, off, o, fmt);
     }
 }
 
@@ -202,7 +198,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
                                                          const float* __restrict__ beta, float eps, int act,
                                                          const float* __restrict__ mask, const float* residual,
                                                          int stable, float* out, uint16_t* __restrict__ out_hi,
-                                                         uint16_t* __restrict__ out_lo) {
+                                                         uint16_t* __restrict__ out_lo, int fmt) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* x = in + (long long)row * C;
@@ -260,7 +256,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
             if (o) reinterpret_cast<float4*>(o)[idx] = r;
             if (out_hi) {
                 const float rv[4] = {r.x, r.y, r.z, r.w};
-                split4_store(out_hi, out_lo, (long long)row * C + idx * 4, rv);
+                split4_store(out_hi, out_lo, (long long)row * C + idx * 4, rv, fmt);
             }
         }
     }
@@ -533,7 +529,8 @@ extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, 
 }
 
 static int conv0_impl(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta, float eps,
-                      float* y, uint16_t* y_hi, uint16_t* y_lo, double* moments, float* scale_shift, void* stream) {
+                      float* y, uint16_t* y_hi, uint16_t* y_lo, double* moments, float* scale_shift, int fmt, void* stream) {
+    if (fmt != AVI_PLANES_BF16 && fmt != AVI_PLANES_F16) return AVI_EINVAL;
     if (!x || !w0 || !gamma || !beta || (!y && !y_hi) || !moments || !scale_shift || B <= 0 || N < K0) return AVI_EINVAL;
     if ((y_hi == nullptr) != (y_lo == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -543,20 +540,20 @@ static int conv0_impl(const float* x, int B, int N, const float* w0, const float
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, w0, gamma, beta, T0, eps,
                        scale_shift);
     hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + C0_TT - 1) / C0_TT, B), dim3(256), 0, s, x, N, T0, w0,
-                       scale_shift, y, y_hi, y_lo);
+                       scale_shift, y, y_hi, y_lo, fmt);
     return avi_launch_status();
 }
 
 extern "C" int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma,
                                  const float* beta, float eps, float* y, double* moments, float* scale_shift,
                                  void* stream) {
-    return conv0_impl(x, B, N, w0, gamma, beta, eps, y, nullptr, nullptr, moments, scale_shift, stream);
+    return conv0_impl(x, B, N, w0, gamma, beta, eps, y, nullptr, nullptr, moments, scale_shift, AVI_PLANES_BF16, stream);
 }
 
 extern "C" int avi_conv0_gn_gelu_planes(const float* x, int B, int N, const float* w0, const float* gamma,
                                         const float* beta, float eps, uint16_t* y_hi, uint16_t* y_lo, double* moments,
-                                        float* scale_shift, void* stream) {
-    return conv0_impl(x, B, N, w0, gamma, beta, eps, nullptr, y_hi, y_lo, moments, scale_shift, stream);
+                                        float* scale_shift, int plane_fmt, void* stream) {
+    return conv0_impl(x, B, N, w0, gamma, beta, eps, nullptr, y_hi, y_lo, moments, scale_shift, plane_fmt, stream);
 }
 
 extern "C" int avi_interp_layernorm(const float* in, int B, int Tin, int C, int Tout, const float* gamma,
@@ -589,10 +586,10 @@ extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* g
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr);
+                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
     else
         hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr);
+                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
     return avi_launch_status();
 }
 
@@ -612,11 +609,12 @@ extern "C" int avi_splitk_epilogue(const float* parts, int nparts, long long par
 }
 
 extern "C" int avi_layernorm_planes(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
-                                    float* out, uint16_t* out_hi, uint16_t* out_lo, void* stream) {
+                                    float* out, uint16_t* out_hi, uint16_t* out_lo, int plane_fmt, void* stream) {
     if (!in || !out_hi || !out_lo || rows <= 0 || C <= 0 || (C & 3) || C > 1024) return AVI_EINVAL;
+    if (plane_fmt != AVI_PLANES_BF16 && plane_fmt != AVI_PLANES_F16) return AVI_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
                        rows, C, gamma, beta, eps, AVI_ACT_NONE, (const float*)nullptr, (const float*)nullptr, 0, out,
-                       out_hi, out_lo);
+                       out_hi, out_lo, plane_fmt);
     return avi_launch_status();
 }
 

@@ -299,7 +299,7 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
         return AVI_EINVAL;
     if (planes) {
         if ((g.lda & 7) || (g.sAo & 7) || (g.sAi & 7) || (reinterpret_cast<uintptr_t>(g.Ahi) & 15)) return AVI_EINVAL;
-        if ((g.prec & 0xff) == AVI_PREC_BF16X3 && (!g.Alo || (reinterpret_cast<uintptr_t>(g.Alo) & 15))) return AVI_EINVAL;
+        if ((g.prec & 0xff) != AVI_PREC_BF16 && (!g.Alo || (reinterpret_cast<uintptr_t>(g.Alo) & 15))) return AVI_EINVAL;
         if (g.N <= 64) return AVI_EINVAL;          // the LDS-DMA kernel's weight tile is 128 rows
     } else {
         if (g.Chi) return AVI_EINVAL;               // plane output is implemented by the LDS-DMA kernel only
@@ -308,7 +308,8 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     if ((g.sWo & 7) || (g.sWi & 7) || (reinterpret_cast<uintptr_t>(g.Whi) & 15)) return AVI_EINVAL;
     if ((g.prec & 0xff) == AVI_PREC_BF16X3 && (!g.Wlo || (reinterpret_cast<uintptr_t>(g.Wlo) & 15))) return AVI_EINVAL;
     const int prec = g.prec & 0xff;   // bits 8,9: timing diagnostics (skip loads / skip MFMAs), results then invalid
-    if (prec != AVI_PREC_BF16 && prec != AVI_PREC_BF16X3) return AVI_EINVAL;
+    if (prec != AVI_PREC_BF16 && prec != AVI_PREC_BF16X3 && prec != AVI_PREC_F16X2) return AVI_EINVAL;
+    if (prec == AVI_PREC_F16X2 && !planes) return AVI_EINVAL;      // the 2-term fp16 mode exists on the plane-operand kernels
     if ((g.scale == nullptr) != (g.shift == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (planes) {   // AVI_GEMM_KERNEL=2 keeps the one-phase LDS-DMA kernel, 4 / 5 force one ping-pong tile shape
@@ -324,6 +325,7 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
         if (pick == 1) return avi_gemm_pp_launch(g, s);
         if (pick == 2) return avi_gemm_pp192_launch(g, 192, s);
         if (pick == 3) return avi_gemm_pp192_launch(g, 256, s);
+        if (prec == AVI_PREC_F16X2) return AVI_EINVAL;             // K does not tile for the ping-pong kernels
         return avi_gemm_dma_launch(g, s);
     }
     // 64-column tiles for narrow outputs and for grids of up to two 128-column workgroups per CU: these launches are

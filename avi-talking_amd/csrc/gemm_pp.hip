@@ -35,6 +35,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
 constexpr int BM = 256, BN = 256, NTHR = 512;
 constexpr int HALF_BYTES = 128 * 128;          // 128 rows x 128 B
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // X0 X1 W0 W1
@@ -50,7 +52,10 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NS>
+// F16 (with NS = 2): the opt-in 2-term fp16 mode AVI_PREC_F16X2 - activation planes are fp16 hi/lo, the weight is ONE fp16
+// plane (the "lo" half of a staged weight row is a second copy nobody multiplies), y = w.xh + w.xl: two MFMAs per
+// product instead of three; plane outputs are split into fp16 hi/lo.
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const int tilesM, const int tilesN) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     const uint16_t* __restrict__ Ahi = g.Ahi + zo * g.sAo + zi * g.sAi;
     const uint16_t* __restrict__ Alo = (NS == 2) ? g.Alo + zo * g.sAo + zi * g.sAi : Ahi;
     const uint16_t* __restrict__ Whi = g.Whi + zo * g.sWo + zi * g.sWi;
-    const uint16_t* __restrict__ Wlo = (NS == 2) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
+    const uint16_t* __restrict__ Wlo = (NS == 2 && !F16) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
 
     // ---- LDS-DMA source pointers: half tile `kind`, pieces wave and wave + 8 (1 KiB = 8 rows x 128 B each).
     //      lane -> LDS row R = 8 piece + lane/8 of the half tile, LDS chunk lane%8 <- source chunk c = lane%8 ^ (R&7).
@@ -150,7 +155,11 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
 #pragma unroll
             for (int bl = 0; bl < 4; ++bl) {
                 f32x4 c = acc[nh * 2 + al][mh * 4 + bl];
-                if (NS == 2) {
+                if (F16) {
+                    const f16x8 wv = __builtin_bit_cast(f16x8, wh[al]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, __builtin_bit_cast(f16x8, xl[bl]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, __builtin_bit_cast(f16x8, xh[bl]), c, 0, 0, 0);
+                } else if (NS == 2) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[al], xh[bl], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[al], xl[bl], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[al], xh[bl], c, 0, 0, 0);
@@ -340,10 +349,11 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
                     uint32_t h[4], l[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
-                        const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
-                        h[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-                        l[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                        uint16_t h0, h1, l0, l1;
+                        avi_split_hl(v[2 * j], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h0, l0);
+                        avi_split_hl(v[2 * j + 1], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h1, l1);
+                        h[j] = h0 | ((uint32_t)h1 << 16);
+                        l[j] = l0 | ((uint32_t)l1 << 16);
                     }
                     const long long o = (long long)m * g.ldc + n;
                     *reinterpret_cast<uint4*>(Chi + o) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -355,11 +365,9 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
                     if (n + j < g.N) {
                         const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
                         if (C) C[(long long)m * g.ldc + n + j] = y;
-                        if (Chi) {
-                            const __bf16 hb = (__bf16)y;
-                            Chi[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, hb);
-                            Clo[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, (__bf16)(y - (float)hb));
-                        }
+                        if (Chi)
+                            avi_split_hl(y, F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, Chi[(long long)m * g.ldc + n + j],
+                                         Clo[(long long)m * g.ldc + n + j]);
                     }
             }
         }
@@ -378,12 +386,12 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
 #endif
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 int launch(const AviGemm& g, hipStream_t s) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     static AviLdsGrant lds_grant;
-    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp_kernel<NS>), SMEM_BYTES);
-    hipLaunchKernelGGL((gemm_pp_kernel<NS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp_kernel<NS, F16>), SMEM_BYTES);
+    hipLaunchKernelGGL((gemm_pp_kernel<NS, F16>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();
 }
@@ -392,10 +400,11 @@ int launch(const AviGemm& g, hipStream_t s) {
 
 // true when the ping-pong kernel can take the problem (K tiles come in pairs)
 bool avi_gemm_pp_ok(const AviGemm& g) {
-    const int kt = (g.prec & 0xff) == AVI_PREC_BF16X3 ? 32 : 64;
+    const int kt = (g.prec & 0xff) == AVI_PREC_BF16 ? 64 : 32;
     return g.Ahi && g.K % (2 * kt) == 0 && g.K >= 2 * kt;
 }
 
 int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s) {
+    if ((g.prec & 0xff) == AVI_PREC_F16X2) return launch<2, true>(g, s);
     return (g.prec & 0xff) == AVI_PREC_BF16X3 ? launch<2>(g, s) : launch<1>(g, s);
 }

@@ -22,6 +22,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
 // NT = n-tiles per wave: 3 -> 128 x 192 tile, 4 -> 128 x 256 tile (189 tiles at M = 8000, N = 768: ONE round when the
 // sampler holds 32 of the 256 CUs, where 252 tiles of 128 x 192 need two)
 constexpr int BM = 128, NTHR = 512;
@@ -48,7 +50,8 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NS, int NT>
+// F16 (with NS = 2): the opt-in 2-term fp16 mode AVI_PREC_F16X2, as in gemm_pp.hip.
+template <int NS, int NT, bool F16 = false>
 __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN) {
     constexpr int BN = Geo<NT>::BN, STAGE_BYTES = Geo<NT>::STAGE_BYTES, EP_STRIDE = Geo<NT>::EP_STRIDE,
                   EP_SLAB = Geo<NT>::EP_SLAB;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     const uint16_t* __restrict__ Ahi = g.Ahi + zo * g.sAo + zi * g.sAi;
     const uint16_t* __restrict__ Alo = (NS == 2) ? g.Alo + zo * g.sAo + zi * g.sAi : Ahi;
     const uint16_t* __restrict__ Whi = g.Whi + zo * g.sWo + zi * g.sWi;
-    const uint16_t* __restrict__ Wlo = (NS == 2) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
+    const uint16_t* __restrict__ Wlo = (NS == 2 && !F16) ? g.Wlo + zo * g.sWo + zi * g.sWi : Whi;
 
     // ---- LDS-DMA source pointers (1 KiB pieces = 8 rows x 128 B; lane -> row 8 piece + lane/8, source chunk
     //      c = lane%8 ^ (row&7)).  X0 / X1: piece = wave (64 rows: wave-row R/32 owns rows R%32 of its m-half);
@@ -158,7 +161,11 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
 #pragma unroll
             for (int bl = 0; bl < 2; ++bl) {
                 f32x4 c = acc[a][mh * 2 + bl];
-                if (NS == 2) {
+                if (F16) {
+                    const f16x8 wv = __builtin_bit_cast(f16x8, wh[a]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, __builtin_bit_cast(f16x8, xl[bl]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, __builtin_bit_cast(f16x8, xh[bl]), c, 0, 0, 0);
+                } else if (NS == 2) {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[a], xh[bl], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xl[bl], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[a], xh[bl], c, 0, 0, 0);
@@ -276,10 +283,11 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                 uint32_t h[2], l[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
-                    const __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
-                    h[j] = __builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-                    l[j] = __builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+                    uint16_t h0, h1, l0, l1;
+                    avi_split_hl(v[2 * j], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h0, l0);
+                    avi_split_hl(v[2 * j + 1], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h1, l1);
+                    h[j] = h0 | ((uint32_t)h1 << 16);
+                    l[j] = l0 | ((uint32_t)l1 << 16);
                 }
                 const long long o = (long long)m * g.ldc + n;
                 *reinterpret_cast<uint2*>(Chi + o) = make_uint2(h[0], h[1]);
@@ -291,23 +299,21 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                 if (n + j < g.N) {
                     const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
                     if (C) C[(long long)m * g.ldc + n + j] = y;
-                    if (Chi) {
-                        const __bf16 hb = (__bf16)y;
-                        Chi[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, hb);
-                        Clo[(long long)m * g.ldc + n + j] = __builtin_bit_cast(uint16_t, (__bf16)(y - (float)hb));
-                    }
+                    if (Chi)
+                        avi_split_hl(y, F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, Chi[(long long)m * g.ldc + n + j],
+                                     Clo[(long long)m * g.ldc + n + j]);
                 }
         }
     }
 }
 
-template <int NS, int NT>
+template <int NS, int NT, bool F16 = false>
 int launch(const AviGemm& g, hipStream_t s) {
     constexpr int BN = Geo<NT>::BN, SMEM_BYTES = Geo<NT>::SMEM_BYTES;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     static AviLdsGrant lds_grant;
-    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT>), SMEM_BYTES);
-    hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT, F16>), SMEM_BYTES);
+    hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT, F16>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();
 }
@@ -316,12 +322,13 @@ int launch(const AviGemm& g, hipStream_t s) {
 
 // true when the 128-row ping-pong kernels can take the problem (K tiles come in threes)
 bool avi_gemm_pp192_ok(const AviGemm& g) {
-    const int kt = (g.prec & 0xff) == AVI_PREC_BF16X3 ? 32 : 64;
+    const int kt = (g.prec & 0xff) == AVI_PREC_BF16 ? 64 : 32;
     return g.Ahi && g.K % (3 * kt) == 0;
 }
 
 // bn = 192 or 256
 int avi_gemm_pp192_launch(const AviGemm& g, int bn, hipStream_t s) {
+    if ((g.prec & 0xff) == AVI_PREC_F16X2) return bn == 256 ? launch<2, 4, true>(g, s) : launch<2, 3, true>(g, s);
     const bool x3 = (g.prec & 0xff) == AVI_PREC_BF16X3;
     if (bn == 256) return x3 ? launch<2, 4>(g, s) : launch<1, 4>(g, s);
     return x3 ? launch<2, 3>(g, s) : launch<1, 3>(g, s);

@@ -184,7 +184,7 @@ class TalkingHeadWrapper:
         self.device = torch.device(device)
         # EMOTE's resampled wav2vec2 rounds the output length up (AudioEncoders.py:19-20)
         self.audio_model = Wav2Vec2Model(audio_state_dict, device=device, prec=prec, length_mode="ceil")
-        self.head = EmoteHead(head_state_dict, device=device, prec=prec)
+        self.head = EmoteHead(head_state_dict, device=device, prec=ops.fp32_operand_prec(prec))
         self.joint_norm = joint_norm        # AudioEncoders.py:170-178: HF processor sees ONE (B*L) array
 
     def forward_audio(self, sample):

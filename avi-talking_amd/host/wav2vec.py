@@ -34,7 +34,12 @@ class Wav2Vec2Model:
 
     def __init__(self, state_dict, device="cuda", prec=ops.PREC_BF16X3, length_mode="int"):
         self.device = torch.device(device)
-        self.prec = prec
+        # prec = PREC_F16X2 (opt-in): the plane-operand GEMMs (conv layers 1-6, the encoder's projections: 98 % of the
+        # FLOPs) run the 2-term fp16 mode on fp16 hi/lo planes; the small fp32-operand GEMMs (feature projection,
+        # pos-conv) stay on the 3-term bf16 split
+        self.prec_planes = prec
+        self.fmt = ops.plane_fmt(prec)
+        self.prec = prec = ops.PREC_BF16X3 if (prec & 0xff) == ops.PREC_F16X2 else prec
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
         # Activation format.  Conv stack: bf16 hi/lo planes feeding the 256x256 ping-pong GEMM (gemm_pp.hip), each
         # layer's epilogue emitting the next layer's planes (AVI_W2V_PLANES=0: fp32 activations + gemm.hip).
@@ -100,10 +105,10 @@ class Wav2Vec2Model:
             for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
                 h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
             return h
-        h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b)
+        h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b, fmt=self.fmt)
         n = len(self.convs)
         for i, (pw, k, s) in enumerate(zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:])):
-            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec, out_planes=i + 1 < n)
+            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec_planes, out_planes=i + 1 < n)
         return h
 
     def output_length(self, L50, frame_num=None):
@@ -136,16 +141,17 @@ class Wav2Vec2Model:
                 h = ops.layernorm(h, *ly.ln2, out=h)
             return h
         # LayerNorm outputs feed a big GEMM (qkv / ffn1) AND the residual: emitted as split planes + fp32
-        h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h)
+        P, F = self.prec_planes, self.fmt
+        h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=F)
         d = HIDDEN // HEADS
         for ly in self.layers:   # every projection on the 128x192 ping-pong GEMM, every activation split once
-            qkv = ops.linear_planes(hp_, ly.qkv, prec=self.prec)                      # (B,T,2304) fp32
-            att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5)                    # planes
-            h = ops.linear_planes(att, ly.out, residual=h, prec=self.prec)
-            h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h)
-            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=self.prec, out_planes=True)
-            h = ops.linear_planes(f, ly.ff2, residual=h, prec=self.prec)
-            h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h)
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=P)                              # (B,T,2304) fp32
+            att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5, fmt=F)             # planes
+            h = ops.linear_planes(att, ly.out, residual=h, prec=P)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h, fmt=F)
+            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=P, out_planes=True)
+            h = ops.linear_planes(f, ly.ff2, residual=h, prec=P)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=F)
         return h
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libavi_talking_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_LRELU02, ACT_RELU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
-PREC_BF16, PREC_BF16X3 = 1, 3
+PREC_BF16, PREC_F16X2, PREC_BF16X3 = 1, 2, 3
+PLANES_BF16, PLANES_F16 = 0, 1
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -95,12 +96,12 @@ SIGNATURES = {
     "avi_conv0_gn_gelu": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "avi_interp_layernorm": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_interp_layernorm_planes": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
-    "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "avi_conv0_gn_gelu_planes": [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "avi_flame_vertices": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "avi_flame_pack_basis": [_vp, _vp, _vp, _vp],
     "avi_transpose_pack_split": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "avi_splitk_epilogue": [_vp, _i, _ll, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp],
-    "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "avi_layernorm_planes": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_layernorm_act": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
@@ -110,8 +111,8 @@ SIGNATURES = {
     "avi_mean_tokens": [_vp, _i, _i, _i, _vp, _vp],
     "avi_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "avi_attention_d64": [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp],
-    "avi_attention_d64_planes": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp],
-    "avi_attention_d64_planes_biased": [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "avi_attention_d64_planes": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _i, _vp],
+    "avi_attention_d64_planes_biased": [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "avi_prior_forward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_sample": [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],

@@ -8,8 +8,19 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, PREC_BF16,  # noqa: F401
-                  PREC_BF16X3)
+from .lib import (ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, PLANES_BF16,  # noqa: F401
+                  PLANES_F16, PREC_BF16, PREC_BF16X3, PREC_F16X2)
+
+
+def fp32_operand_prec(prec):
+    """Precision of the small fp32-operand GEMMs (gemm.hip) under a pipeline precision: the opt-in fp16 mode exists on
+    the plane-operand kernels only, everything else stays on the 3-term bf16 split."""
+    return PREC_BF16X3 if (prec & 0xff) == PREC_F16X2 else prec
+
+
+def plane_fmt(prec):
+    """Plane format the plane-operand GEMMs of precision ``prec`` consume (and emit)."""
+    return PLANES_F16 if (prec & 0xff) == PREC_F16X2 else PLANES_BF16
 
 
 def _f32c(t, name):
@@ -42,6 +53,21 @@ class PackedWeight:
     @property
     def nbytes(self):
         return self.hi.numel() * 4
+
+    def f16_plane(self):
+        """[N_pad][K] fp16 (int16 storage): the single weight plane of the opt-in 2-term fp16 GEMM (AVI_PREC_F16X2).
+        Built on first use from hi + lo (= the fp32 weight to 2^-16), once per model."""
+        if getattr(self, "_f16", None) is None:
+            w = self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
+            self._f16 = w.to(torch.float16).view(torch.int16).contiguous()
+        return self._f16
+
+    def planes_for(self, prec):
+        """(Whi, Wlo) device pointers for a plane-operand GEMM of precision ``prec``."""
+        if (prec & 0xff) == PREC_F16X2:
+            p = self.f16_plane().data_ptr()
+            return p, p
+        return self.hi.data_ptr(), self.lo.data_ptr()
 
 
 def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
@@ -284,48 +310,51 @@ def attention_d64(qkv, H, scale, out=None):
     return out
 
 
-def attention_d64_planes(qkv, H, scale, bias_mode=0, slopes=None, period=1):
+def attention_d64_planes(qkv, H, scale, bias_mode=0, slopes=None, period=1, fmt=PLANES_BF16):
     """Head-dim-64 attention whose result is written as split planes (operand of the out_proj GEMM)."""
     qkv = _f32c(qkv, "qkv")
     B, T, ld = qkv.shape
     if ld != 3 * H * 64:
         raise ValueError(f"attention_d64_planes: last dim {ld} != 3*H*64")
-    out = Planes((B, T, H * 64), qkv.device)
+    out = Planes((B, T, H * 64), qkv.device, fmt)
     if bias_mode == 0:
         L.check(L.load().avi_attention_d64_planes(qkv.data_ptr(), B, H, T, ld, scale, None, out.hi.data_ptr(),
-                                                  out.lo.data_ptr(), H * 64, L.stream_ptr()),
+                                                  out.lo.data_ptr(), H * 64, fmt, L.stream_ptr()),
                 "avi_attention_d64_planes")
     else:
         L.require_gpu(slopes)
         L.check(L.load().avi_attention_d64_planes_biased(qkv.data_ptr(), B, H, T, ld, scale, bias_mode, L.ptr(slopes),
                                                          period, None, out.hi.data_ptr(), out.lo.data_ptr(), H * 64,
-                                                         L.stream_ptr()), "avi_attention_d64_planes_biased")
+                                                         fmt, L.stream_ptr()), "avi_attention_d64_planes_biased")
     return out
 
 
 # ------------------------------------------------------------------ split-plane activations (x = hi + lo, bf16 each)
 class Planes:
-    """An activation stored as two bf16 planes (int16 storage), the operand format of the LDS-DMA GEMM."""
+    """An activation stored as two 16-bit planes (int16 storage), x = hi + lo: bf16 (PLANES_BF16) or fp16 (PLANES_F16),
+    the operand format of the LDS-DMA GEMMs."""
 
-    def __init__(self, shape, device):
+    def __init__(self, shape, device, fmt=PLANES_BF16):
         self.shape = tuple(shape)
+        self.fmt = fmt
         self.hi = torch.empty(self.shape, dtype=torch.int16, device=device)
         self.lo = torch.empty(self.shape, dtype=torch.int16, device=device)
 
     def float(self):
-        return self.hi.view(torch.bfloat16).float() + self.lo.view(torch.bfloat16).float()
+        dt = torch.float16 if self.fmt == PLANES_F16 else torch.bfloat16
+        return self.hi.view(dt).float() + self.lo.view(dt).float()
 
 
-def conv0_gn_gelu_planes(x, w0, gamma, beta, eps=1e-5):
+def conv0_gn_gelu_planes(x, w0, gamma, beta, eps=1e-5, fmt=PLANES_BF16):
     x = _f32c(x, "x")
     B, N = x.shape
     T0 = (N - 10) // 5 + 1
-    out = Planes((B, T0, 512), x.device)
+    out = Planes((B, T0, 512), x.device, fmt)
     mom = torch.empty((65 * B,), dtype=torch.float64, device=x.device)
     ss = torch.empty((1024 * B,), dtype=torch.float32, device=x.device)
     L.check(L.load().avi_conv0_gn_gelu_planes(x.data_ptr(), B, N, _f32c(w0, "w0").data_ptr(), gamma.data_ptr(),
                                               beta.data_ptr(), eps, out.hi.data_ptr(), out.lo.data_ptr(), mom.data_ptr(),
-                                              ss.data_ptr(), L.stream_ptr()), "avi_conv0_gn_gelu_planes")
+                                              ss.data_ptr(), fmt, L.stream_ptr()), "avi_conv0_gn_gelu_planes")
     return out
 
 
@@ -336,13 +365,16 @@ def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_
         raise ValueError("conv1d_cl_planes: weight does not match the input / N too narrow for the LDS-DMA kernel")
     Tout = (Tin - ksize) // stride + 1
     dev = xp.hi.device
+    if xp.fmt != plane_fmt(prec):
+        raise ValueError("conv1d_cl_planes: the input planes are not in the format this precision consumes")
     if out_planes:
-        out = Planes((B, Tout, pw.N), dev)
+        out = Planes((B, Tout, pw.N), dev, plane_fmt(prec))
         c_args = dict(Chi=out.hi.data_ptr(), Clo=out.lo.data_ptr())
     else:
         out = torch.empty((B, Tout, pw.N), dtype=torch.float32, device=dev)
         c_args = dict(C_=out.data_ptr())
-    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+    whi, wlo = pw.planes_for(prec)
+    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=stride * Cin, Whi=whi, Wlo=wlo,
              ldc=pw.N, M=Tout, N=pw.N, K=pw.K, bias=L.ptr(pw.bias), act=act, prec=prec, batch=B, sA=(Tin * Cin, 0),
              sC=(Tout * pw.N, 0), **c_args)
     return out
@@ -359,29 +391,32 @@ def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=Non
         M *= d
     if residual is not None and _f32c(residual, "residual").numel() != M * pw.N:
         raise ValueError("linear_planes: bad residual shape")
+    if xp.fmt != plane_fmt(prec):
+        raise ValueError("linear_planes: the input planes are not in the format this precision consumes")
     if out_planes:
-        out = Planes(tuple(xp.shape[:-1]) + (pw.N,), xp.hi.device)
+        out = Planes(tuple(xp.shape[:-1]) + (pw.N,), xp.hi.device, plane_fmt(prec))
         c_args = dict(Chi=out.hi.data_ptr(), Clo=out.lo.data_ptr())
     else:
         if out is None:
             out = torch.empty(tuple(xp.shape[:-1]) + (pw.N,), dtype=torch.float32, device=xp.hi.device)
         c_args = dict(C_=out.data_ptr())
-    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
+    whi, wlo = pw.planes_for(prec)
+    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=whi, Wlo=wlo,
              ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act, prec=prec, **c_args)
     return out
 
 
-def layernorm_planes(x, gamma, beta, eps=1e-5, out=None, want_f32=True):
+def layernorm_planes(x, gamma, beta, eps=1e-5, out=None, want_f32=True, fmt=PLANES_BF16):
     """LayerNorm emitting the result as fp32 (optional) and as split planes for the next GEMM."""
     x = _f32c(x, "x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     if want_f32 and out is None:
         out = torch.empty_like(x)
-    pl = Planes(x.shape, x.device)
+    pl = Planes(x.shape, x.device, fmt)
     L.check(L.load().avi_layernorm_planes(x.data_ptr(), rows, Cc, L.ptr(gamma), L.ptr(beta), eps,
                                           out.data_ptr() if want_f32 else None, pl.hi.data_ptr(), pl.lo.data_ptr(),
-                                          L.stream_ptr()), "avi_layernorm_planes")
+                                          fmt, L.stream_ptr()), "avi_layernorm_planes")
     return (out if want_f32 else None), pl
 
 

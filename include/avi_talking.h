@@ -41,6 +41,12 @@ extern "C" {
 /* precision codes: how fp32 operands are fed to the bf16 matrix cores */
 #define AVI_PREC_BF16 1   /* x,w rounded to bf16; 1 MFMA per product; ~4e-3 relative */
 #define AVI_PREC_BF16X3 3 /* x=xh+xl, w=wh+wl; xh*wh + xh*wl + xl*wh; ~1e-5 relative (parity mode) */
+#define AVI_PREC_F16X2 2  /* OPT-IN: x=xh+xl (fp16 planes), w rounded to ONE fp16 plane (Whi; Wlo ignored); xh*w + xl*w:
+                             two MFMAs per product, weight rounding 2^-12 (the reference itself runs fp16 autocast).
+                             Plane-operand GEMMs only (Ahi/Alo given); Chi/Clo outputs are fp16 hi/lo planes. */
+/* split-plane activation formats (x = hi + lo, 16-bit patterns) of the plane-producing entry points */
+#define AVI_PLANES_BF16 0
+#define AVI_PLANES_F16 1
 
 const char* avi_version(void);
 
@@ -100,10 +106,10 @@ int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, int joint, 
  * w0 [512][10], gamma/beta [512]; moments: scratch >= 65*B doubles; scale_shift: scratch >= 1024*B floats. */
 int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
                       float eps, float* y, double* moments, float* scale_shift, void* stream);
-/* same, result as bf16 hi/lo planes [B][T0][512] (the A operand format of the LDS-DMA GEMM) */
+/* same, result as hi/lo planes [B][T0][512] (the A operand format of the LDS-DMA GEMM; plane_fmt = AVI_PLANES_*) */
 int avi_conv0_gn_gelu_planes(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
                              float eps, uint16_t* y_hi, uint16_t* y_lo, double* moments, float* scale_shift,
-                             void* stream);
+                             int plane_fmt, void* stream);
 
 /* 50->25 Hz resample (F.interpolate linear, align_corners=True; models/lib/wav2vec.py:67-73) fused
  * with LayerNorm(C) of the feature projection (HF Wav2Vec2FeatureProjection).
@@ -125,9 +131,10 @@ int avi_splitk_epilogue(const float* parts, int nparts, long long part_stride, i
                         const float* gamma, const float* beta, float eps, int do_ln, int act, const float* residual,
                         float* out, void* stream);
 
-/* LayerNorm whose result is written as fp32 (out, may be NULL) and as bf16 hi/lo planes (the next GEMM's operand) */
+/* LayerNorm whose result is written as fp32 (out, may be NULL) and as hi/lo planes (the next GEMM's operand;
+ * plane_fmt = AVI_PLANES_*) */
 int avi_layernorm_planes(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
-                         float* out, uint16_t* out_hi, uint16_t* out_lo, void* stream);
+                         float* out, uint16_t* out_hi, uint16_t* out_lo, int plane_fmt, void* stream);
 /* out[r] = act(LN(in[r])) + residual[r]  (BrainNetwork blocks: Linear -> LayerNorm -> GELU -> +residual,
  * models/diffusion_prior.py:64-76,106-110).  residual may be NULL; in == out allowed. */
 int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, const float* beta, float eps,
@@ -174,12 +181,12 @@ int avi_attention_d64(const float* qkv, int B, int H, int T, int ld, float scale
 /* Same attention, result as split bf16 planes out_hi/out_lo [B][T][ldo] (x = hi + lo; `out` fp32 optional, may be NULL):
  * the activation format of the LDS-DMA GEMMs, so encoder.layers.*.attention.out_proj reads it without conversion. */
 int avi_attention_d64_planes(const float* qkv, int B, int H, int T, int ld, float scale, float* out,
-                             uint16_t* out_hi, uint16_t* out_lo, int ldo, void* stream);
+                             uint16_t* out_hi, uint16_t* out_lo, int ldo, int plane_fmt, void* stream);
 /* Same, under the bias modes of avi_attention (slopes [H] device for modes 1, 2).  Mode 2 with zero slopes and
  * period 1 is the causal mask of the CLIP text transformer behind FrozenCLIPEmbedder (models/diffusion_prior.py:52-53). */
 int avi_attention_d64_planes_biased(const float* qkv, int B, int H, int T, int ld, float scale, int bias_mode,
                                     const float* slopes, int period, float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                    int ldo, void* stream);
+                                    int ldo, int plane_fmt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion prior.  Replaces VersatileDiffusionPriorNetwork.forward (models/diffusion_prior.py:223-313),

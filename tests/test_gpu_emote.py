@@ -103,3 +103,25 @@ def test_batched_pipeline_equals_oracle_utterance_by_utterance(gpu):
     a = joint.run(pcm.to(gpu), voxel.to(gpu), noise.to(gpu))["predicted_exp"].cpu()[1]
     b_ = joint.run(pcm2.to(gpu), voxel.to(gpu), noise.to(gpu))["predicted_exp"].cpu()[1]
     assert not torch.equal(a, b_)
+
+
+def test_two_term_fp16_pipeline_coefficients(gpu):
+    """OPT-IN AVI_PREC_F16X2 through the whole sampling path (audio -> coefficients) at config[1] sub-batch size against
+    the oracle: the predicted coefficients stay under north_star's 1e-3 max-abs gate (own parity line of the mode; the
+    default and the headline remain the 3-term bf16 split at ~2e-5)."""
+    from avi_talking_amd import ops, weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    from oracle import emote as OE, prior as OP, wav2vec2 as OW
+    wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
+    B, T = 2, 100
+    g = torch.Generator().manual_seed(91)
+    pcm = (torch.randn(B, T * 640, generator=g) * 3000).to(torch.int16)
+    voxel, noise = torch.randn(B, 768, generator=g), torch.randn(101, B, 1, 128, generator=g)
+    out = SamplingPipeline(wa, wh, wp, device=gpu, prec=ops.PREC_F16X2).run(pcm.to(gpu), voxel.to(gpu), noise.to(gpu))
+    feat = OW.forward(wa, OW.normalize_audio(pcm, joint=False), frame_num=T)
+    te, _ = OP.brain_network(wp, voxel)
+    ref = OE.forward(wh, feat, OP.p_sample_loop(wp, te.view(B, 1, 128), noise))
+    e = max((out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
+            (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
+    print(f"f16x2 pipeline: max-abs coefficient err {e:.2e}")
+    assert e < 1e-3

@@ -46,3 +46,21 @@ def test_wav2vec2_activation_formats(gpu, monkeypatch, conv_planes, tf_planes):
     err = (out - ref).abs().max().item()
     print(f"conv planes={conv_planes} transformer planes={tf_planes}: last_hidden_state err {err:.3e}")
     assert err < 1e-3
+
+
+def test_wav2vec2_two_term_fp16_mode(gpu):
+    """The OPT-IN 2-term fp16 mode (AVI_PREC_F16X2: fp16 hi/lo activation planes x ONE fp16 weight plane, two MFMAs per
+    product; the reference itself runs fp16 autocast) against the fp32 oracle: hidden state within 2e-3, an order of
+    magnitude better than single-pass bf16 and 50x worse than the default 3-term split (which stays the headline)."""
+    from avi_talking_amd.weights import make_wav2vec2_weights
+    from avi_talking_amd.host.wav2vec import Wav2Vec2Model
+    from avi_talking_amd import ops
+    from oracle import wav2vec2 as O
+    w = make_wav2vec2_weights(0)
+    x = torch.randn(2, 32000, generator=torch.Generator().manual_seed(5))
+    ref = O.forward(w, x, return_intermediates=True)
+    out = Wav2Vec2Model(w, device=gpu, prec=ops.PREC_F16X2)(x.to(gpu), "vocaset")
+    e_conv = (out.extract_features.cpu() - ref["conv"].transpose(1, 2)).abs().max().item()
+    e_out = (out.last_hidden_state.cpu() - ref["last_hidden_state"]).abs().max().item()
+    print(f"f16x2: conv err {e_conv:.3e}, last_hidden_state err {e_out:.3e}")
+    assert e_conv < 2e-3 and e_out < 5e-3
