@@ -95,9 +95,13 @@ class GradSync:
     (train_diffusion_prior.py:338,442,450)."""
 
     def __init__(self, layout, depth=6, n_blocks=4, process_group=None):
+        import os
         self.layout, self.pg = layout, process_group
         self.expected = [layout.span(a, b) for a, b in grad_spans(depth, n_blocks)]
         self.works, self.done = [], []
+        # AVI_DP_FORCE_COLLECTIVES=1: issue the collectives with a single rank too (rehearsal of the RCCL path on a
+        # one-GPU box; an all-reduce over one rank leaves the buffer unchanged)
+        self.force = os.environ.get("AVI_DP_FORCE_COLLECTIVES") == "1"
 
     def world(self):
         import torch.distributed as dist
@@ -105,13 +109,17 @@ class GradSync:
             return dist.get_world_size(self.pg)
         return 1
 
+    def _collectives(self):
+        import torch.distributed as dist
+        return self.world() > 1 or (self.force and dist.is_available() and dist.is_initialized())
+
     def ready(self, G, first, last):
         span = self.layout.span(first, last)
         i = len(self.done)
         if i >= len(self.expected) or span != self.expected[i]:
             raise RuntimeError(f"gradient span {first}..{last} announced out of order (position {i})")
         self.done.append(span)
-        if self.world() > 1:
+        if self._collectives():
             self.works += bucketed_allreduce(G, [span], self.pg)
 
     def finish(self, G):
@@ -120,7 +128,7 @@ class GradSync:
             raise RuntimeError(f"{len(self.expected) - len(self.done)} gradient spans were never announced")
         self.done = []
         world = self.world()
-        if world > 1:
+        if self._collectives():
             L_ = self.layout
             self.works += bucketed_allreduce(G, [(L_.n_decay, L_.numel)], self.pg)
             for w in self.works:
