@@ -27,7 +27,10 @@ class SamplingPipeline:
     def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False):
         self.device = torch.device(device)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
-        self.prior = InstructDiffusionPrior.from_state_dict(prior_sd, device=device, prec=ops.fp32_operand_prec(prec))
+        # the opt-in fp16 mode also stores the sampler's attention matrices as one fp16 plane
+        self.prior = InstructDiffusionPrior.from_state_dict(
+            prior_sd, device=device, prec=ops.fp32_operand_prec(prec),
+            attn_fp16=True if (prec & 0xff) == ops.PREC_F16X2 else None)
         # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
         self.side = torch.cuda.Stream(device=self.device, priority=-1)
         self.prior.time_table()          # built once, outside any capture
