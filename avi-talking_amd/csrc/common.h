@@ -118,6 +118,17 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Sum / max over a 256-thread workgroup (4 waves) through 4 LDS words; every thread gets the result.  `slot` tells
+// consecutive reductions of one kernel apart (no barrier is needed between them: each uses its own 4 words).
+template <bool MAX>
+__device__ __forceinline__ float block256_reduce(float v, float (*red)[4], int slot) {
+    v = MAX ? wave_max(v) : wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[slot][threadIdx.x >> 6] = v;
+    __syncthreads();
+    return MAX ? fmaxf(fmaxf(red[slot][0], red[slot][1]), fmaxf(red[slot][2], red[slot][3]))
+               : (red[slot][0] + red[slot][1]) + (red[slot][2] + red[slot][3]);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -192,50 +192,57 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ LayerNorm helpers (one wave per row)
-template <int MAXV>  // MAXV float4 per lane held in registers: C <= 256*MAXV
+// BR = false: one wave per row (4 rows per workgroup), MAXV float4 per lane: C <= 256 MAXV.
+// BR = true : one WORKGROUP per row, MAXV float4 per thread: C <= 1024 MAXV.  For a few wide rows (the aligner's 64 x 4096)
+//             one wave per row leaves 16 waves on the chip walking 80 KB each (24 us); a workgroup per row takes 6.
+template <int MAXV, bool BR = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int rows, int C,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int act,
                                                          const float* __restrict__ mask, const float* residual,
                                                          int stable, float* out, uint16_t* __restrict__ out_hi,
                                                          uint16_t* __restrict__ out_lo, int fmt) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ float red[3][4];
+    constexpr int LN = BR ? 256 : 64;
+    const int row = BR ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6), lane = BR ? threadIdx.x : threadIdx.x & 63;
     if (row >= rows) return;
+    auto rsum = [&](float t, int slot) { return BR ? block256_reduce<false>(t, red, slot) : wave_sum(t); };
+    auto rmax = [&](float t, int slot) { return BR ? block256_reduce<true>(t, red, slot) : wave_max(t); };
     const float* x = in + (long long)row * C;
     const int nv = C >> 2;
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         v[i] = idx < nv ? reinterpret_cast<const float4*>(x)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (stable) {  // dalle2 LayerNorm(stable=True): x / x.amax(-1) first
         float mx = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
-            if (lane + 64 * i < nv) mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-        const float inv = 1.f / wave_max(mx);
+            if (lane + LN * i < nv) mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        const float inv = 1.f / rmax(mx, 0);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) { v[i].x *= inv; v[i].y *= inv; v[i].z *= inv; v[i].w *= inv; }
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
-    const float mean = wave_sum(s) / C;
+    const float mean = rsum(s, 1) / C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         if (idx < nv) {
             const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
             q += a * a + b * b + c * c + d * d;
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float rstd = rsqrtf(rsum(q, 2) / C + eps);
     float* o = out ? out + (long long)row * C : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         if (idx < nv) {
             float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gamma) g = reinterpret_cast<const float4*>(gamma)[idx];
@@ -587,9 +594,9 @@ extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* g
     if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
                            stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
+    else   // a workgroup per row
+        hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(rows), block, 0, s, in, rows, C, gamma, beta, eps, act, mask,
+                           residual, stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
     return avi_launch_status();
 }
 

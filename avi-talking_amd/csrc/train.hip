@@ -187,14 +187,18 @@ __global__ void swiglu_bwd_kernel(const float* __restrict__ h, const float* __re
 // forward was  y = act(LN(x*pre)) * mask (+ residual, handled by the caller), LN(u) = (u-mean)*rstd*gamma + beta,
 // pre = 1/amax(x) when `stable` (treated as a constant: dalle2 detaches it).  One wave per row.
 // Outputs dx and per-row stats (mean, rstd, pre) for the parameter-gradient kernel.
-template <int MAXV>
+template <int MAXV, bool BR = false>   // BR: one workgroup per row (see layernorm_kernel in elementwise.hip)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mask, int rows, int C, float eps,
                                                       int act, int stable, const float* dx_add, float* dx,
                                                       float* __restrict__ stats) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ float red[5][4];
+    constexpr int LN = BR ? 256 : 64;
+    const int row = BR ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6), lane = BR ? threadIdx.x : threadIdx.x & 63;
     if (row >= rows) return;
+    auto rsum = [&](float t, int slot) { return BR ? block256_reduce<false>(t, red, slot) : wave_sum(t); };
+    auto rmax = [&](float t, int slot) { return BR ? block256_reduce<true>(t, red, slot) : wave_max(t); };
     const int nv = C >> 2;
     const float4* xp = reinterpret_cast<const float4*>(x + (long long)row * C);
     const float4* dyp = reinterpret_cast<const float4*>(dy + (long long)row * C);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     float pre = 1.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         const float4 t = idx < nv ? xp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
     }
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         float mx = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
-            if (lane + 64 * i < nv) mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
-        pre = 1.f / wave_max(mx);
+            if (lane + LN * i < nv) mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+        pre = 1.f / rmax(mx, 0);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i)
 #pragma unroll
@@ -221,19 +225,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    const float mean = wave_sum(s) / C;
+    const float mean = rsum(s, 1) / C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
-        if (lane + 64 * i < nv)
+        if (lane + LN * i < nv)
 #pragma unroll
             for (int j = 0; j < 4; ++j) q += (v[i][j] - mean) * (v[i][j] - mean);
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float rstd = rsqrtf(rsum(q, 2) / C + eps);
     // g1 = dL/d(LN output) = dy * mask * act'(u);  then the standard LN backward on gamma*g1
     float sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         if (idx < nv) {
             const float4 d = dyp[idx];
             const float4 gm = reinterpret_cast<const float4*>(gamma)[idx];
@@ -255,12 +259,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             for (int j = 0; j < 4; ++j) g1[i][j] = 0.f;
         }
     }
-    sa = wave_sum(sa) / C;
-    sb = wave_sum(sb) / C;
+    sa = rsum(sa, 3) / C;
+    sb = rsum(sb, 4) / C;
     float4* dxp = reinterpret_cast<float4*>(dx + (long long)row * C);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = lane + LN * i;
         if (idx < nv) {
             float o[4];
 #pragma unroll
@@ -813,9 +817,9 @@ extern "C" int avi_layernorm_bwd(const float* x, const float* dy, const float* g
     if (C <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, x, dy, gamma, beta, mask, rows, C, eps, act, stable,
                            dx_add, dx, stats);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, block, 0, s, x, dy, gamma, beta, mask, rows, C, eps, act, stable,
-                           dx_add, dx, stats);
+    else   // a workgroup per row
+        hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(rows), block, 0, s, x, dy, gamma, beta, mask, rows, C, eps, act,
+                           stable, dx_add, dx, stats);
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 15) / 16), dim3(256), 0, s, x, dy, gamma, beta, mask, stats,
                        rows, C, act, dgamma, dbeta, accumulate);
     return avi_launch_status();
