@@ -215,10 +215,16 @@ class _Lin:
                      C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
         if not self.need_dx:
             return None
+        return self.bwd_dx(dy, dx_residual)
+
+    def bwd_dx(self, dy, dx_residual=None):
+        """dx = dy . W (+ residual) alone: the parameter gradient of this layer is formed elsewhere (the prior's layers
+        defer theirs to one batched launch per matrix, PriorTrainer._deferred_dw)."""
+        M = dy.numel() // self.N
         if self._use_skinny(M, self.K, self.N):
             return self._skinny(dy, self.N, self.hiT.data_ptr(), self.loT.data_ptr(), M, self.K, self.N,
                                 residual=dx_residual, kslice=self._kslice(self.N))
-        dx = torch.empty((M, self.K), dtype=torch.float32, device=dev)
+        dx = torch.empty((M, self.K), dtype=torch.float32, device=dy.device)
         ops.gemm_raw(A=dy.data_ptr(), lda=self.N, Whi=self.hiT.data_ptr(), Wlo=self.loT.data_ptr(), C_=dx.data_ptr(),
                      ldc=self.K, M=M, N=self.K, K=self.N, R=L.ptr(dx_residual), ldr=self.K)
         return dx
@@ -333,6 +339,7 @@ class PriorTrainer:
         self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
         self.sync = GradSync(S.layout, depth, n_blocks, process_group)
         self._ttable = None
+        self._ws = {}
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
@@ -341,6 +348,57 @@ class PriorTrainer:
         ``first`` through ``last`` (contiguous in the flat buffer): start their all-reduce now, so it overlaps
         with the rest of backward (the 67 M-parameter aligner blocks dominate the 311 MB volume)."""
         self.sync.ready(self.store.G, first, last)
+
+    # ------------------------------------------------------------------ deferred parameter gradients of the prior layers
+    _DW = (("qkv", 640, DIM), ("out", DIM, 512), ("w1", 1024, DIM), ("w2", DIM, 512))     # (lin, N out, K in)
+
+    def _dw_ws(self, B):
+        """Persistent per-batch-size workspace: the inputs x and output gradients dy of the four matrices of every
+        prior layer, stacked over the layers, written in place by the kernels that produce them; their transposes; and
+        a device job table per matrix (addresses never change, so it is built once).  With these the 24 weight-gradient
+        GEMMs of the 6 layers and their 24 transpose launches collapse into 4 + 4 launches at the end of the prior's
+        backward pass: dW is a leaf of the graph, nothing in backward waits for it."""
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        R, dev, Ld = 3 * B, self.device, self.depth
+        ws = {}
+        for name, N, K in self._DW:
+            Kp = 64 if K <= 64 else (K + 127) // 128 * 128
+            x = torch.empty((Ld, R, K), dtype=torch.float32, device=dev)
+            dy = torch.empty((Ld, R, N), dtype=torch.float32, device=dev)
+            dyT = torch.empty((Ld, N, R), dtype=torch.float32, device=dev)
+            xhi = torch.empty((Ld, Kp, R), dtype=torch.int16, device=dev)
+            xlo = torch.empty_like(xhi)
+            jobs = (L.AviTransposeJob * (2 * Ld))()
+            total = 0
+            for l in range(Ld):
+                for jb, (src, rows_, cols, kw) in zip((jobs[2 * l], jobs[2 * l + 1]),
+                                                      ((dy[l], R, N, dict(out=dyT[l].data_ptr())),
+                                                       (x[l], R, K, dict(hi=xhi[l].data_ptr(), lo=xlo[l].data_ptr(), C_pad=Kp)))):
+                    jb.in_, jb.R, jb.C = src.data_ptr(), rows_, cols
+                    for k_, v_ in kw.items():
+                        setattr(jb, k_, v_)
+                    jb.first_block = total
+                    total += jb.blocks()
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+            ws[name] = dict(x=x, dy=dy, dyT=dyT, xhi=xhi, xlo=xlo, Kp=Kp, table=(raw, 2 * Ld, total))
+        self._ws[B] = ws
+        return ws
+
+    def _deferred_dw(self, ws, R):
+        """dW[l] = dy[l]^T . x[l] for the four matrices of all layers: one transpose launch + one batched GEMM each."""
+        S, so = self.store, L.load()
+        c0, c1 = self.c + "layers.0.", self.c + "layers.1."
+        wname = {"qkv": "0.to_q.weight", "out": "0.to_out.0.weight", "w1": "1.1.weight", "w2": "1.5.weight"}
+        for name, N, K in self._DW:
+            w = ws[name]
+            raw, n, total = w["table"]
+            L.check(so.avi_transpose_table(raw.data_ptr(), n, total, L.stream_ptr()), "avi_transpose_table")
+            stride = (S.offset[c1 + wname[name]] - S.offset[c0 + wname[name]]) if self.depth > 1 else 0
+            ops.gemm_raw(A=w["dyT"].data_ptr(), lda=R, Whi=w["xhi"].data_ptr(), Wlo=w["xlo"].data_ptr(),
+                         C_=S.gptr(c0 + wname[name]), ldc=K, M=N, N=K, K=R, batch=self.depth, sA=(N * R, 0),
+                         sW=(w["Kp"] * R, 0), sC=(stride, 0))
 
     # ------------------------------------------------------------------ helpers
     def refresh(self):
@@ -367,19 +425,19 @@ class PriorTrainer:
                                                L.stream_ptr()), "pack")
         self.refresh()
 
-    def _ln(self, x, g, b=None, act=ops.ACT_NONE, mask=None, residual=None, stable=0):
+    def _ln(self, x, g, b=None, act=ops.ACT_NONE, mask=None, residual=None, stable=0, out=None):
         S = self.store
-        out = torch.empty_like(x)
+        out = torch.empty_like(x) if out is None else out
         C = x.shape[-1]
         L.check(L.load().avi_layernorm_ex(x.data_ptr(), x.numel() // C, C, S.ptr(g), S.ptr(b) if b else 0, 1e-5, act,
                                           L.ptr(mask), L.ptr(residual), stable, out.data_ptr(), L.stream_ptr()), "ln")
         return out
 
-    def _ln_bwd(self, x, dy, g, b=None, act=ops.ACT_NONE, mask=None, stable=0, dx_add=None):
+    def _ln_bwd(self, x, dy, g, b=None, act=ops.ACT_NONE, mask=None, stable=0, dx_add=None, out=None):
         S = self.store
         C = x.shape[-1]
         rows = x.numel() // C
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x) if out is None else out
         stats = torch.empty(3 * rows, dtype=torch.float32, device=x.device)
         L.check(L.load().avi_layernorm_bwd(x.data_ptr(), dy.data_ptr(), S.ptr(g), S.ptr(b) if b else 0, L.ptr(mask),
                                            rows, C, 1e-5, act, stable, L.ptr(dx_add), dx.data_ptr(), S.gptr(g),
@@ -451,18 +509,19 @@ class PriorTrainer:
         rel_bias = torch.empty((8, 3, 4), dtype=torch.float32, device=dev)
         L.check(so.avi_prior_rel_bias(S.ptr(rel_name), rel_bias.data_ptr(), None, None, 8, 3, st()), "rel_bias")
         saved = []
-        for ly in self.layers:
+        ws = self._dw_ws(B)
+        for li, ly in enumerate(self.layers):
             a, f = ly["a"], ly["f"]
-            n1 = self._ln(tok, a + "norm.g")
+            n1 = self._ln(tok, a + "norm.g", out=ws["qkv"]["x"][li])
             qkv = ly["qkv"].fwd(n1)
-            ao = torch.empty((R, 512), dtype=torch.float32, device=dev)
+            ao = ws["out"]["x"][li]
             L.check(so.avi_prior_attn_fwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
                                           self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), B, ao.data_ptr(), st()), "attn")
             o1 = ly["out"].fwd(ao)
             tokm = self._ln(o1, a + "to_out.1.g", residual=tok)
-            n2 = self._ln(tokm, f + "0.g")
+            n2 = self._ln(tokm, f + "0.g", out=ws["w1"]["x"][li])
             hff = ly["w1"].fwd(n2)
-            sw = torch.empty((R, 512), dtype=torch.float32, device=dev)
+            sw = ws["w2"]["x"][li]
             L.check(so.avi_swiglu_fwd(hff.data_ptr(), R, 512, sw.data_ptr(), st()), "swiglu")
             tok_next = torch.empty_like(tok)
             ops.gemm_raw(A=sw.data_ptr(), lda=512, Whi=S.hi_ptr(f + "5.weight"), Wlo=S.lo_ptr(f + "5.weight"),
@@ -490,23 +549,27 @@ class PriorTrainer:
         dpo = zbuf[4:4 + R * DIM].view(B, 3, DIM)
         L.check(so.avi_copy_rows(dpred.data_ptr(), DIM, None, dpo.data_ptr() + 2 * DIM * 4, 3 * DIM, B, DIM, st()), "dpo")
         dfin = self.cproj.bwd(fin, dpo.view(R, DIM))
-        dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1)
+        # every layer's output gradients land in the stacked workspace (dy of w2 = the gradient arriving at the layer);
+        # only the dX chain runs here, the parameter gradients follow in _deferred_dw
+        dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1, out=ws["w2"]["dy"][self.depth - 1])
         drel = zbuf[4 + R * DIM:4 + R * DIM + 96].view(8, 3, 4)
-        for ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(self.layers), reversed(saved)):
+        for li, ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(range(self.depth)), reversed(self.layers),
+                                                                   reversed(saved)):
             a, f = ly["a"], ly["f"]
-            dsw = ly["w2"].bwd(sw, dtok)
-            dhff = torch.empty_like(hff)
+            dsw = ly["w2"].bwd_dx(dtok)
+            dhff = ws["w1"]["dy"][li]
             L.check(so.avi_swiglu_bwd(hff.data_ptr(), dsw.data_ptr(), R, 512, dhff.data_ptr(), st()), "swiglu_bwd")
-            dn2 = ly["w1"].bwd(n2, dhff)
+            dn2 = ly["w1"].bwd_dx(dhff)
             dtokm = self._ln_bwd(tokm, dn2, f + "0.g", dx_add=dtok)
-            do1 = self._ln_bwd(o1, dtokm, a + "to_out.1.g")
-            dao = ly["out"].bwd(ao, do1)
-            dqkv = torch.empty_like(qkv)
+            do1 = self._ln_bwd(o1, dtokm, a + "to_out.1.g", out=ws["out"]["dy"][li])
+            dao = ly["out"].bwd_dx(do1)
+            dqkv = ws["qkv"]["dy"][li]
             L.check(so.avi_prior_attn_bwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
                                           self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), dao.data_ptr(), B,
                                           dqkv.data_ptr(), S.gptr(a + "null_kv"), drel.data_ptr(), st()), "attn_bwd")
-            dn1 = ly["qkv"].bwd(n1, dqkv)
-            dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm)
+            dn1 = ly["qkv"].bwd_dx(dqkv)
+            dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm, out=ws["w2"]["dy"][li - 1] if li > 0 else None)
+        self._deferred_dw(ws, R)
         # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
         L.check(so.avi_prior_rel_bias(None, None, drel.data_ptr(), S.gptr(rel_name), 8, 3, st()), "rel_bias_bwd")
         dtext = torch.empty((B, DIM), dtype=torch.float32, device=dev)
