@@ -24,7 +24,7 @@ from .talking_head import TalkingHeadWrapper
 
 
 class SamplingPipeline:
-    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False):
+    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None):
         self.device = torch.device(device)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
         # the opt-in fp16 mode also stores the sampler's attention matrices as one fp16 plane
@@ -32,7 +32,7 @@ class SamplingPipeline:
             prior_sd, device=device, prec=ops.fp32_operand_prec(prec),
             attn_fp16=True if (prec & 0xff) == ops.PREC_F16X2 else None)
         # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
-        self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=self.device, priority=-1)
         self.prior.time_table()          # built once, outside any capture
         self._graph = None
         self._static = None

@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing (roofline object)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--secondary-timeout", type=float, default=300.0,
                     help="seconds the roofline / cpu_baseline / flame / train legs may take before the line is printed "
@@ -268,14 +269,16 @@ def main():
         except Exception as e:  # the sampling line above must survive a failure of a secondary measurement
             line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, prec, line["ms_per_step"]))
+    if not args.no_roofline:
+        run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, prec, line["ms_per_step"]))
     if world == 1 and not args.no_cpu_baseline:
         run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
     ref_out = {k: out[k].clone() for k in ("predicted_exp", "predicted_jaw")}
+    side = pipe.side          # a second pipeline of this process keeps the high-priority stream the first one used
     del pipe, out
     torch.cuda.empty_cache()
     if args.prec == "bf16x3" and not args.no_train:
-        run_leg("f16x2_opt_in", lambda: measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args))
+        run_leg("f16x2_opt_in", lambda: measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args, side))
         torch.cuda.empty_cache()
     if not args.no_train:
         run_leg("faceformer", lambda: measure_faceformer(dev))
@@ -625,32 +628,37 @@ def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16):
             "units": units}
 
 
-def measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args):
-    """Secondary, never the headline: the same config[1] pass in the OPT-IN 2-term fp16 mode (AVI_PREC_F16X2: fp16 hi/lo
-    activation planes x one fp16 weight plane on the plane-operand GEMMs; the reference itself runs fp16 autocast), with
-    its own parity line: max-abs difference of its coefficients from the default 3-term pass on the same inputs (the
-    default is 2e-5 from the oracle; tests/test_gpu_emote.py pins this mode below north_star's 1e-3 against the oracle)."""
+def measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args, side=None):
+    """Secondary, never the headline: the same config[1] pass in the OPT-IN fp16 mode (AVI_PREC_F16X2: fp16 hi/lo activation
+    planes x one fp16 weight plane on the plane-operand GEMMs, every sampler matrix one fp16 plane; the reference itself
+    runs fp16 autocast), with its own parity line: max-abs difference of its coefficients from the default 3-term pass on
+    the same inputs (the default is 2e-5 from the oracle; tests/test_gpu_emote.py pins this mode below north_star's 1e-3
+    against the oracle).  The parity line comes from a pipeline built here; the TIMING comes from a child process running
+    this script's own timed region with --prec f16x2 (a second pipeline captured in one process replays 10-30 % slower
+    than the same pipeline in a process of its own - measured 13.8-14.9 vs 11.0-11.1 ms, also over 300 steps - so an
+    in-process figure would not be what a user of the mode gets)."""
+    import subprocess
     from avi_talking_amd import ops
     from avi_talking_amd.host.pipeline import SamplingPipeline
-    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=ops.PREC_F16X2, joint_norm=args.joint_norm)
-    pipe.capture(pcm, voxel, noise)
-    for _ in range(3):
-        o = pipe.replay()
+    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=ops.PREC_F16X2, joint_norm=args.joint_norm, side_stream=side)
+    o = pipe.run(pcm, voxel, noise)
     torch.cuda.synchronize(dev)
-    dt = float("inf")
-    for _ in range(3):                       # best of three blocks of `steps` replays (the chip's clocks settle)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            o = pipe.replay()
-        torch.cuda.synchronize(dev)
-        dt = min(dt, (time.perf_counter() - t0) / args.steps)
     err = max((o["predicted_exp"] - ref_out["predicted_exp"]).abs().max().item(),
               (o["predicted_jaw"] - ref_out["predicted_jaw"]).abs().max().item())
-    del pipe
+    del pipe, o
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.abspath(__file__), "--prec", "f16x2", "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--no-cpu-baseline", "--no-train", "--no-roofline"] + (["--joint-norm"] if args.joint_norm else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AVI_BENCH_FORCE_DIST")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench failed ({r.returncode}): {r.stderr[-200:]}")
+    child = json.loads(lines[0])
     return {"workload": "configs[1] in the opt-in fp16 mode: 2 MFMA per product (fp16 hi/lo activation planes x one fp16 "
                         "weight plane) on conv layers 1-6 and the encoder projections, every sampler matrix one fp16 plane",
-            "dtype": "f16x2", "ms_per_step": round(dt * 1e3, 3),
-            "frames_per_s": round(B_CLIPS * T_FRAMES / dt, 1), "steps": args.steps,
+            "dtype": "f16x2", "ms_per_step": child["ms_per_step"], "frames_per_s": child["value"], "steps": child["steps"],
+            "timed_in": "child process: python bench.py --prec f16x2 (same timed region)",
             "max_abs_coeff_diff_vs_default": float(f"{err:.3e}"), "gate": 1e-3}
 
 
