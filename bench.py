@@ -504,6 +504,19 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
             tsrc = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             break
 
+    busy = {}
+    bpath = os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")
+    if os.path.exists(bpath):
+        with open(bpath) as fh:
+            busy = json.load(fh).get("kernels", {})
+
+    def pmc_busy(name):
+        base = name.split(" ")[0].split("<")[0]
+        tag = name.split("<")[1].split(">")[0] if "<" in name else ""
+        tag = {"NT=3": ", 3,", "NT=4": ", 4,"}.get(tag, tag)
+        hit = busy.get(name) or next((v for k, v in busy.items() if k.startswith(base) and (tag in k if tag else True)), None)
+        return hit["mfma_busy_frac"] if hit else None
+
     def describe(name):
         ms, fl, n = fam[name]
         ach = fl / (ms * 1e-3) / 1e12
@@ -519,7 +532,10 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
                 "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "ms_per_step": round(ms / reps, 3), "frac_of_step": round(ms / reps / step_ms, 3),
                 "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
-                "traffic": t["hbm_bytes_per_launch"] if t else None}
+                "traffic": t["hbm_bytes_per_launch"] if t else None,
+                # matrix-pipe busy cycles / (kernel cycles x 1024 SIMDs), rocprofv3 PMC pass (kernels serialised by the
+                # profiler, i.e. the kernel alone on the chip): profiles/r02_pmc_mfma.json
+                "mfma_busy_pmc": pmc_busy(name)}
 
     entries = [describe(k) for k in fam]
     if srec:
@@ -542,7 +558,8 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
             "launches_per_step": 1, "avg_launch_us": round(sms * 1e3, 1), "ms_per_step": round(sms, 3),
             "frac_of_step": round(sms / step_ms, 3), "algorithmic_bytes_per_launch": nbytes,
             "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
-            "traffic": t["hbm_bytes_per_launch"] if t else None})
+            "traffic": t["hbm_bytes_per_launch"] if t else None,
+            "mfma_busy_pmc": (next((v for k, v in busy.items() if k.startswith("prior_sample")), {}) or {}).get("mfma_busy_frac")})
     entries.sort(key=lambda e: -e["ms_per_step"])
     out = entries[0]
     out["others"] = entries[1:]
