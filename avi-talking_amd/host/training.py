@@ -340,6 +340,10 @@ class PriorTrainer:
         self.sync = GradSync(S.layout, depth, n_blocks, process_group)
         self._ttable = None
         self._ws = {}
+        import os
+        # AVI_TRAIN_FUSED_FWD=0: the forward of the denoiser as the chain of ~55 launches it used to be (A/B switch, tests)
+        self.fused_forward = os.environ.get("AVI_TRAIN_FUSED_FWD", "1") == "1"
+        self.fwd_samples_per_group = int(os.environ.get("AVI_TRAIN_FWD_SPG", "2"))   # 32 workgroups at B = 64
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
@@ -383,8 +387,73 @@ class PriorTrainer:
                     total += jb.blocks()
             raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
             ws[name] = dict(x=x, dy=dy, dyT=dyT, xhi=xhi, xlo=xlo, Kp=Kp, table=(raw, 2 * Ld, total))
+        # what the one-launch forward (avi_prior_train_forward) stores besides the four x arrays above
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        ws["fwd"] = dict(tok_in=f(Ld, R, DIM), qkv=f(Ld, R, 640), o1=f(Ld, R, DIM), tokm=f(Ld, R, DIM), hff=f(Ld, R, 1024),
+                         tok_out=f(R, DIM), fin=f(R, DIM), po=f(R, DIM), rel_bias=f(8, 3, 4))
         self._ws[B] = ws
         return ws
+
+    def _fused_forward_setup(self):
+        """Constants of the one-launch forward, built once: fragment-major plane buffers of the denoiser's matrices with
+        the device job table that re-packs them from the flat bf16 hi/lo parameter planes every step, and the struct of
+        small-vector pointers into the flat parameter buffer (addresses never change)."""
+        S, dev = self.store, self.device
+        c = self.c
+        mats = []
+        for l in range(self.depth):
+            a, f = c + f"layers.{l}.0.", c + f"layers.{l}.1."
+            mats += [(a + "to_q.weight", 640, DIM), (a + "to_out.0.weight", DIM, 512), (f + "1.weight", 1024, DIM),
+                     (f + "5.weight", DIM, 512)]
+        mats.append((c + "project_out.weight", DIM, DIM))
+        jobs = (L.AviPlaneJob * len(mats))()
+        self._fplanes = []
+        total = 0
+        for jb, (name, N, K) in zip(jobs, mats):
+            hi = torch.empty(N * K, dtype=torch.int16, device=dev)
+            lo = torch.empty_like(hi)
+            self._fplanes.append((hi, lo))
+            jb.src_hi, jb.src_lo, jb.dst_hi, jb.dst_lo = S.hi_ptr(name), S.lo_ptr(name), hi.data_ptr(), lo.data_ptr()
+            jb.N, jb.K, jb.first_block, jb.transpose = N, K, total, 0
+            total += jb.blocks()
+        self._fjobs = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), len(mats), total)
+        pl = L.AviPriorPlanes()
+        for l in range(self.depth):
+            lp = pl.layer[l]
+            (lp.qkv_hi, lp.qkv_lo), (lp.out_hi, lp.out_lo), (lp.w1_hi, lp.w1_lo), (lp.w2_hi, lp.w2_lo) = [
+                (h.data_ptr(), o.data_ptr()) for h, o in self._fplanes[4 * l:4 * l + 4]]
+        pl.proj_hi, pl.proj_lo = (t.data_ptr() for t in self._fplanes[-1])
+        cw = L.AviPriorWeights()
+        cw.depth, cw.timesteps = self.depth, 100
+        cw.rot_cos, cw.rot_sin = self.rot_cos.data_ptr(), self.rot_sin.data_ptr()
+        for l in range(self.depth):
+            a, f = c + f"layers.{l}.0.", c + f"layers.{l}.1."
+            ly = cw.layer[l]
+            ly.norm_g, ly.null_kv, ly.out_g, ly.ff_g = S.ptr(a + "norm.g"), S.ptr(a + "null_kv"), S.ptr(a + "to_out.1.g"), S.ptr(f + "0.g")
+        cw.final_g = S.ptr(c + "norm.g")
+        self._fplanes_struct, self._fweights = pl, cw
+
+    def _fused_forward(self, ws, tok, B, rel_bias):
+        """tokens -> all six layers -> project_out in two launches (plane re-pack + avi_prior_train_forward).  Returns
+        (saved, tok_out, fin, po) in the form the backward pass below expects."""
+        import ctypes as C
+        so = L.load()
+        if getattr(self, "_fjobs", None) is None:
+            self._fused_forward_setup()
+        raw, n, total = self._fjobs
+        L.check(so.avi_pack_fragment_planes(raw.data_ptr(), n, total, L.stream_ptr()), "avi_pack_fragment_planes")
+        fw = ws["fwd"]
+        d = L.AviPriorTrainDump()
+        d.tok0 = tok.data_ptr()
+        d.tok_in, d.qkv, d.o1, d.tokm, d.hff = (fw[k].data_ptr() for k in ("tok_in", "qkv", "o1", "tokm", "hff"))
+        d.n1, d.ao, d.n2, d.sw = (ws[k]["x"].data_ptr() for k in ("qkv", "out", "w1", "w2"))
+        d.tok_out, d.fin, d.po = fw["tok_out"].data_ptr(), fw["fin"].data_ptr(), fw["po"].data_ptr()
+        self._fweights.rel_bias = rel_bias.data_ptr()
+        L.check(so.avi_prior_train_forward(C.byref(self._fweights), C.byref(self._fplanes_struct), C.byref(d), B,
+                                           self.fwd_samples_per_group, L.stream_ptr()), "avi_prior_train_forward")
+        saved = [(fw["tok_in"][l], ws["qkv"]["x"][l], fw["qkv"][l], ws["out"]["x"][l], fw["o1"][l], fw["tokm"][l],
+                  ws["w1"]["x"][l], fw["hff"][l], ws["w2"]["x"][l]) for l in range(self.depth)]
+        return saved, fw["tok_out"], fw["fin"], fw["po"]
 
     def _deferred_dw(self, ws, R):
         """dW[l] = dy[l]^T . x[l] for the four matrices of all layers: one transpose launch + one batched GEMM each."""
@@ -506,30 +575,33 @@ class PriorTrainer:
                                         S.ptr("net.null_image_embed"), S.ptr("net.learned_query"), B, x0.data_ptr(),
                                         tok.data_ptr(), st()), "tokens_fwd")
         rel_name = self.c + "rel_pos_bias.relative_attention_bias.weight"
-        rel_bias = torch.empty((8, 3, 4), dtype=torch.float32, device=dev)
-        L.check(so.avi_prior_rel_bias(S.ptr(rel_name), rel_bias.data_ptr(), None, None, 8, 3, st()), "rel_bias")
-        saved = []
         ws = self._dw_ws(B)
-        for li, ly in enumerate(self.layers):
-            a, f = ly["a"], ly["f"]
-            n1 = self._ln(tok, a + "norm.g", out=ws["qkv"]["x"][li])
-            qkv = ly["qkv"].fwd(n1)
-            ao = ws["out"]["x"][li]
-            L.check(so.avi_prior_attn_fwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
-                                          self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), B, ao.data_ptr(), st()), "attn")
-            o1 = ly["out"].fwd(ao)
-            tokm = self._ln(o1, a + "to_out.1.g", residual=tok)
-            n2 = self._ln(tokm, f + "0.g", out=ws["w1"]["x"][li])
-            hff = ly["w1"].fwd(n2)
-            sw = ws["w2"]["x"][li]
-            L.check(so.avi_swiglu_fwd(hff.data_ptr(), R, 512, sw.data_ptr(), st()), "swiglu")
-            tok_next = torch.empty_like(tok)
-            ops.gemm_raw(A=sw.data_ptr(), lda=512, Whi=S.hi_ptr(f + "5.weight"), Wlo=S.lo_ptr(f + "5.weight"),
-                         C_=tok_next.data_ptr(), ldc=DIM, M=R, N=DIM, K=512, R=tokm.data_ptr(), ldr=DIM)
-            saved.append((tok, n1, qkv, ao, o1, tokm, n2, hff, sw))
-            tok = tok_next
-        fin = self._ln(tok, self.c + "norm.g", stable=1)
-        po = self.cproj.fwd(fin)
+        rel_bias = ws["fwd"]["rel_bias"]
+        L.check(so.avi_prior_rel_bias(S.ptr(rel_name), rel_bias.data_ptr(), None, None, 8, 3, st()), "rel_bias")
+        if self.fused_forward:
+            saved, tok, fin, po = self._fused_forward(ws, tok, B, rel_bias)
+        else:
+            saved = []
+            for li, ly in enumerate(self.layers):
+                a, f = ly["a"], ly["f"]
+                n1 = self._ln(tok, a + "norm.g", out=ws["qkv"]["x"][li])
+                qkv = ly["qkv"].fwd(n1)
+                ao = ws["out"]["x"][li]
+                L.check(so.avi_prior_attn_fwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
+                                              self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), B, ao.data_ptr(), st()), "attn")
+                o1 = ly["out"].fwd(ao)
+                tokm = self._ln(o1, a + "to_out.1.g", residual=tok)
+                n2 = self._ln(tokm, f + "0.g", out=ws["w1"]["x"][li])
+                hff = ly["w1"].fwd(n2)
+                sw = ws["w2"]["x"][li]
+                L.check(so.avi_swiglu_fwd(hff.data_ptr(), R, 512, sw.data_ptr(), st()), "swiglu")
+                tok_next = torch.empty_like(tok)
+                ops.gemm_raw(A=sw.data_ptr(), lda=512, Whi=S.hi_ptr(f + "5.weight"), Wlo=S.lo_ptr(f + "5.weight"),
+                             C_=tok_next.data_ptr(), ldc=DIM, M=R, N=DIM, K=512, R=tokm.data_ptr(), ldr=DIM)
+                saved.append((tok, n1, qkv, ao, o1, tokm, n2, hff, sw))
+                tok = tok_next
+            fin = self._ln(tok, self.c + "norm.g", stable=1)
+            po = self.cproj.fwd(fin)
         pred = torch.empty((B, DIM), dtype=torch.float32, device=dev)                 # tokens[:, -1] (:311)
         L.check(so.avi_copy_rows(po.data_ptr() + 2 * DIM * 4, 3 * DIM, None, pred.data_ptr(), DIM, B, DIM, st()), "pred")
 

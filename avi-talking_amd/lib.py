@@ -82,6 +82,19 @@ class AviFaceformerWeights(C.Structure):
                                     "coeff_mean", "coeff_std")])
 
 
+class AviPriorTrainDump(C.Structure):
+    _fields_ = [(n, _vp) for n in ("tok0", "tok_in", "n1", "qkv", "ao", "o1", "tokm", "n2", "hff", "sw", "tok_out", "fin",
+                                   "po")]
+
+
+class AviPlaneJob(C.Structure):
+    _fields_ = [("src_hi", _vp), ("src_lo", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("N", _i), ("K", _i),
+                ("first_block", _i), ("transpose", _i)]
+
+    def blocks(self):
+        return (self.N * self.K // 8 + 255) // 256
+
+
 class AviFaceformerPlanes(C.Structure):
     _fields_ = [(n, _vp) for n in ("wo_hi", "wo_lo", "w1_hi", "w1_lo", "w2_hi", "w2_lo", "wr_hi", "wr_lo", "wf_t", "bf",
                                    "qkv0", "x0")]
@@ -124,6 +137,8 @@ SIGNATURES = {
     "avi_faceformer_decode_steps": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "avi_prior_train_forward": [_vp, _vp, _vp, _i, _i, _vp],
+    "avi_pack_fragment_planes": [_vp, _i, _i, _vp],
     "avi_zero": [_vp, _ll, _vp],
     "avi_copy_rows": [_vp, _ll, _vp, _vp, _ll, _i, _i, _vp],
     "avi_prior_rel_bias": [_vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -335,6 +335,29 @@ int avi_layernorm_ex(const float* in, int rows, int C, const float* gamma, const
 int avi_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mask,
                       int rows, int C, float eps, int act, int stable, const float* dx_add, float* dx, float* dgamma,
                       float* dbeta, int accumulate, float* stats, void* stream);   /* dx = dLN/dx + dx_add (or NULL) */
+/* The training forward of the 3-token denoiser in ONE launch (the pass p_losses differentiates,
+ * models/diffusion_prior.py:119-313,369-400): token rows in, every intermediate the backward pass needs out.  Arrays are
+ * [3B][C] per layer, stacked over the layers ([depth][3B][C]); `qkv` holds the projections BEFORE the rotary rotation.
+ * `w` supplies the small vectors (LayerNorm gains, null_kv, the gathered rel_bias, rotary tables, final_g), `p` the
+ * fragment-major bf16 hi/lo planes of the CURRENT weights (every *_lo non-NULL), re-packed each step by
+ * avi_pack_fragment_planes. */
+typedef struct AviPriorTrainDump {
+    const float* tok0;                 /* [3B][128] token rows (avi_prior_tokens_fwd) */
+    float *tok_in, *n1, *qkv, *ao, *o1, *tokm, *n2, *hff, *sw;   /* C = 128, 128, 640, 512, 128, 128, 128, 1024, 512 */
+    float *tok_out, *fin, *po;         /* [3B][128]: input of the final LayerNorm, its output, project_out */
+} AviPriorTrainDump;
+int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorPlanes* p, const AviPriorTrainDump* d, int B,
+                            int samples_per_group, void* stream);
+/* Table-driven re-layout of row-major [N][K] 16-bit planes into the fragment-major order of AviPriorPlanes (transpose != 0:
+ * the source is the [K][N] plane of the transposed matrix).  jobs_dev: device array; first_block = running sum of
+ * ceil(N*K/8/256) over the jobs; N % 16 == 0, K % 32 == 0. */
+typedef struct AviPlaneJob {
+    const uint16_t *src_hi, *src_lo;
+    uint16_t *dst_hi, *dst_lo;
+    int N, K, first_block, transpose;
+} AviPlaneJob;
+int avi_pack_fragment_planes(const AviPlaneJob* jobs_dev, int njobs, int total_blocks, void* stream);
+
 /* Data movement of the step, so that a captured training step contains library kernels only
  * (tests/test_gpu_library_only.py): p[0..n) = 0 (p 16-byte aligned) */
 int avi_zero(float* p, long long n, void* stream);

@@ -164,3 +164,28 @@ def test_checkpoint_round_trip_and_flame_pkl(gpu, tmp_path):
         d = pickle.load(f)
     assert set(d) == {"shape", "expression", "jaw_pose", "global_pose"} and d["global_pose"].shape == (5, 3)
     assert not d["global_pose"].any()
+
+
+def test_fused_forward_equals_launch_chain(gpu, monkeypatch):
+    """The one-launch training forward of the denoiser (avi_prior_train_forward) and the launch chain it replaces give
+    the same losses, predictions and gradients (both 3-term bf16: differences at rounding level)."""
+    from avi_talking_amd.host.training import PriorTrainer
+    from avi_talking_amd.weights import make_prior_weights
+    w = make_prior_weights(3)
+    g = torch.Generator().manual_seed(123)
+    B = 64
+    voxel, target = torch.randn(B, 768, generator=g).to(gpu), (torch.randn(B, 1, 128, generator=g) * 0.3).to(gpu)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AVI_TRAIN_FUSED_FWD", fused)
+        tr = PriorTrainer(w, device=gpu)
+        assert tr.fused_forward == (fused == "1")
+        rand = tr.draw(B, generator=torch.Generator(device=gpu).manual_seed(9))
+        o = tr.forward_backward(voxel, target, rand["times"], rand["noise"], 0.005, rand["brain_keep"], rand["image_keep"],
+                                rand["dropout_masks"])
+        tr.allreduce_grads()
+        outs.append((o["loss_prior"].item(), o["loss_nce"].item(), o["pred"].clone(), tr.store.G.clone()))
+    (lp1, ln1, p1, g1), (lp0, ln0, p0, g0) = outs
+    assert abs(lp1 - lp0) < 1e-4 * abs(lp0) and abs(ln1 - ln0) < 1e-5
+    assert (p1 - p0).abs().max().item() < 1e-4
+    assert (g1 - g0).abs().max().item() < 2e-4 * g0.abs().max().item()
