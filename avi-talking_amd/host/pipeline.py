@@ -45,9 +45,9 @@ class SamplingPipeline:
                                         cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
                                         noise=noise)
 
-    def run(self, pcm, voxel, noise):
-        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128)
-        -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
+    def _body(self, pcm, voxel, noise, clip_voxels=None):
+        """Everything up to the join of the two branches: -> (audio features (B,T,768), sampled style (B,1,128)).
+        ``clip_voxels``: the aligner's output when it was computed ahead (pipelined replay); None = compute it here."""
         B, N = pcm.shape
         T = N // 640
         cur = torch.cuda.current_stream(self.device)
@@ -56,8 +56,8 @@ class SamplingPipeline:
         #    workgroups of the audio branch and the sampler starts late (+0.4 ms per step, measured);
         #    AVI_ALIGNER_SIDE=1 selects that arrangement for tests/test_gpu_fullsize.py, which pins that overlapping
         #    short matrix-core launches with conv layer 0 no longer corrupts it (build.py: no packed-FP32 instructions).
-        aligner_on_side = os.environ.get("AVI_ALIGNER_SIDE", "0") == "1"
-        if not aligner_on_side:
+        aligner_on_side = os.environ.get("AVI_ALIGNER_SIDE", "0") == "1" and clip_voxels is None
+        if not aligner_on_side and clip_voxels is None:
             clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
         # 2. fork: the sampler (32 workgroups for ~12 ms) on the side stream, the audio encoder on this one
         self.side.wait_stream(cur)
@@ -77,7 +77,13 @@ class SamplingPipeline:
             ops.CU_BUDGET = 0
         # 3. join
         cur.wait_stream(self.side)
-        out = self.talking_head.head(sample["audio_feature"], style)
+        return sample["audio_feature"], style
+
+    def run(self, pcm, voxel, noise):
+        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128)
+        -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
+        feat, style = self._body(pcm, voxel, noise)
+        out = self.talking_head.head(feat, style)
         out["style_emb"] = style
         return out
 
@@ -100,3 +106,63 @@ class SamplingPipeline:
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
         return self._out
+
+    # ---- software-pipelined replay: the serial ends of a pass run beside its neighbours
+    def capture_pipelined(self, pcm, voxel, noise, warmup=2):
+        """Three graphs instead of one.  A pass begins with the aligner (0.17 ms of split-K launches that depend on the text
+        feature alone) and ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip almost idle);
+        between them the two long branches (sampler || audio encoder) keep the chip busy.  Captured as `align`, `body` and
+        `head` and replayed on three streams, the aligner of pass k+1 runs during pass k's branches and the head of pass k
+        beside the start of pass k+1's branches: back-to-back passes cost max(sampler, audio) each.  Hand-offs go through
+        private copies (the aligner's output, the body's two results), guarded by events; every pass still does all of
+        its work and the results are bit-identical to `replay()` (tests/test_gpu_fullsize.py)."""
+        from .. import lib as L
+        self._static = (pcm.clone(), voxel.clone(), noise.clone())
+        for _ in range(warmup):
+            self.run(*self._static)
+        torch.cuda.synchronize(self.device)
+        dev = self.device
+        self._s_align, self._s_body, self._s_head = (torch.cuda.Stream(device=dev) for _ in range(3))
+        self._e_align, self._e_cv_taken, self._e_body, self._e_taken = (torch.cuda.Event() for _ in range(4))
+        B = voxel.shape[0]
+        self._g_align = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_align):
+            self._cv_stage, _ = self.prior.voxel2clip(self._static[1], need_projection=False)
+        self._cv = torch.empty_like(self._cv_stage)
+        self._g_body = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_body):
+            self._feat, self._style = self._body(*self._static, clip_voxels=self._cv)
+        self._h_feat, self._h_style = torch.empty_like(self._feat), torch.empty_like(self._style)
+        self._g_head = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_head):       # pools are NOT shared: the three graphs run concurrently
+            self._pout = self.talking_head.head(self._h_feat, self._h_style)
+            self._pout["style_emb"] = self._h_style
+
+        def copy(src, dst):
+            C_ = src.shape[-1]
+            L.check(L.load().avi_copy_rows(src.data_ptr(), C_, None, dst.data_ptr(), C_, src.numel() // C_, C_,
+                                           L.stream_ptr()), "avi_copy_rows")
+        self._copy = copy
+        torch.cuda.synchronize(dev)
+        return self
+
+    def replay_pipelined(self):
+        """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised)."""
+        with torch.cuda.stream(self._s_align):
+            self._s_align.wait_event(self._e_cv_taken)   # the previous body has taken the previous aligner output
+            self._g_align.replay()
+            self._e_align.record(self._s_align)
+        with torch.cuda.stream(self._s_body):
+            self._s_body.wait_event(self._e_align)
+            self._copy(self._cv_stage, self._cv)
+            self._e_cv_taken.record(self._s_body)
+            self._s_body.wait_event(self._e_taken)       # the previous head has copied the previous body's results
+            self._g_body.replay()
+            self._e_body.record(self._s_body)
+        with torch.cuda.stream(self._s_head):
+            self._s_head.wait_event(self._e_body)
+            self._copy(self._feat, self._h_feat)
+            self._copy(self._style, self._h_style)
+            self._e_taken.record(self._s_head)
+            self._g_head.replay()
+        return self._pout

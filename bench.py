@@ -144,6 +144,9 @@ def main():
                     help="bf16x3 = 3-term split bf16 MFMA (2e-5 on the coefficients; default and headline); f16x2 = opt-in "
                          "2-term fp16 (6e-4, inside the 1e-3 gate); bf16 = 1 term (fails the gate)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="replay the pass as ONE graph, passes strictly one after the other (default: three graphs on three "
+                         "streams, the serial ends of a pass - aligner, head - run beside its neighbours' long branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing (roofline object)")
@@ -201,9 +204,12 @@ def main():
         step = lambda: pipe.run(pcm, voxel, noise)
         for _ in range(2):
             step()
-    else:
+    elif args.no_pipeline:
         pipe.capture(pcm, voxel, noise)
         step = lambda: pipe.replay()
+    else:
+        pipe.capture_pipelined(pcm, voxel, noise)
+        step = lambda: pipe.replay_pipelined()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -234,7 +240,12 @@ def main():
                                "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
                    "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
                    "audio_normalisation": "joint over the batch" if args.joint_norm else "per clip",
-                   "hipgraph": not args.no_graph, "parallelism": f"dp{world} (independent utterances)"},
+                   "hipgraph": not args.no_graph,
+                   "replay": "eager" if args.no_graph else "one graph per pass" if args.no_pipeline else
+                             "three graphs per pass (aligner, body, head) on three streams: the aligner of pass k+1 runs during "
+                             "pass k and the head of pass k beside the start of pass k+1; every pass does all of its work, "
+                             "results bit-identical to the one-graph replay",
+                   "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
         "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
         "roofline": None, "cpu_baseline": None, "f16x2_opt_in": None, "train": None, "faceformer": None, "flame": None,

@@ -104,3 +104,22 @@ def test_two_stream_reproduction_is_clean(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     counts = [int(m) for m in re.findall(r"iter \d+ \[overlap\].* n (\d+)", out.stdout)]
     assert len(counts) == 4 and all(c == 0 for c in counts), out.stdout[-2000:]
+
+
+def test_pipelined_replay_equals_plain_replay(gpu):
+    """capture_pipelined / replay_pipelined (head of batch k beside the start of batch k+1, two graphs on two streams)
+    returns bit for bit what the single-graph replay returns, pass after pass, at config[1] size."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu)
+    pcm, voxel, noise = (t.to(gpu) for t in _inputs(32, 777))
+    pipe.capture(pcm, voxel, noise)
+    ref = pipe.replay()
+    torch.cuda.synchronize()
+    exp, jaw, style = ref["predicted_exp"].clone(), ref["predicted_jaw"].clone(), ref["style_emb"].clone()
+    pipe.capture_pipelined(pcm, voxel, noise)
+    for _ in range(5):
+        out = pipe.replay_pipelined()
+    torch.cuda.synchronize()
+    assert torch.equal(out["predicted_exp"], exp) and torch.equal(out["predicted_jaw"], jaw)
+    assert torch.equal(out["style_emb"], style)
