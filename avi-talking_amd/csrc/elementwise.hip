@@ -38,11 +38,36 @@ __global__ __launch_bounds__(256) void audio_stats_kernel(const void* __restrict
     const int b = blockIdx.y;
     const long long base = (long long)b * N;
     double s = 0.0, q = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const float x = I16 ? (float)reinterpret_cast<const int16_t*>(pcm)[base + i]
-                            : reinterpret_cast<const float*>(pcm)[base + i];
-        s += x;
-        q += (double)x * x;
+    const int vec = I16 ? 8 : 4;                              // samples per 16-byte load
+    if ((N % vec) == 0) {                                     // every clip starts on a 16-byte boundary
+        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * vec; i < N; i += gridDim.x * blockDim.x * vec) {
+            float x[8];
+            if (I16) {
+                const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const int16_t*>(pcm) + base + i);
+                const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[2 * j] = (float)(int16_t)(w[j] & 0xffffu);
+                    x[2 * j + 1] = (float)(int16_t)(w[j] >> 16);
+                }
+            } else {
+                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(pcm) + base + i);
+                x[0] = r.x, x[1] = r.y, x[2] = r.z, x[3] = r.w;
+                x[4] = x[5] = x[6] = x[7] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s += (double)x[j];
+                q = fma((double)x[j], (double)x[j], q);
+            }
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+            const float x = I16 ? (float)reinterpret_cast<const int16_t*>(pcm)[base + i]
+                                : reinterpret_cast<const float*>(pcm)[base + i];
+            s += x;
+            q += (double)x * x;
+        }
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
@@ -83,45 +108,78 @@ __global__ void audio_apply_kernel(const void* __restrict__ pcm, int N, int B, i
 // (65 sums per clip) replaces a full evaluation of the 512 x T0 activation.
 constexpr int C0 = 512, K0 = 10, ST0 = 5, NMOM = 65;  // 10 first + 55 second moments
 
-__global__ void conv0_moments_kernel(const float* __restrict__ x, int N, int T0, double* __restrict__ mom) {
-    const int b = blockIdx.y;
+// First and second window moments of the audio: mom[j] = sum_t x[5t+j], mom[10 + p(j,i)] = sum_t x[5t+j] x[5t+i] (j <= i).
+// Every thread OWNS one moment (tid % 65) over a third of the workgroup's 512 window positions and keeps its sum in a
+// double: no cross-lane reduction at all.  (One position per lane with 65 wave-wide double reductions per wave cost
+// 100 us for 10 MB of audio.)
+constexpr int MOM_CH = 512;     // window positions per workgroup
+constexpr int MOM_LDS = (MOM_CH + 24) * ST0 + K0 + 1;            // + zero padding read by the last runs, + the constant 1
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ x, int N, int T0,
+                                                             double* __restrict__ mom) {
+    __shared__ float sx[MOM_LDS];
+    __shared__ double part[3][NMOM + 1];
+    const int b = blockIdx.y, t0 = blockIdx.x * MOM_CH, t1 = min(T0, t0 + MOM_CH);
     const float* xb = x + (long long)b * N;
-    float s1[K0], s2[55];
+    const int nload = (t1 - t0 - 1) * ST0 + K0;
+    {   // branch-free staging: clamped addresses, every load of a thread in flight at once, zeros past the chunk
+        constexpr int NL = (MOM_LDS + 255) / 256;
+        float v[NL];
 #pragma unroll
-    for (int j = 0; j < K0; ++j) s1[j] = 0.f;
+        for (int u = 0; u < NL; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            v[u] = xb[t0 * ST0 + min(i, nload - 1)];
+        }
 #pragma unroll
-    for (int j = 0; j < 55; ++j) s2[j] = 0.f;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T0; t += gridDim.x * blockDim.x) {
-        float w[K0];
-#pragma unroll
-        for (int j = 0; j < K0; ++j) w[j] = xb[t * ST0 + j];
-        int p = 0;
-#pragma unroll
-        for (int j = 0; j < K0; ++j) {
-            s1[j] += w[j];
-#pragma unroll
-            for (int i = j; i < K0; ++i) s2[p++] += w[j] * w[i];
+        for (int u = 0; u < NL; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < MOM_LDS) sx[i] = i < nload ? v[u] : (i == MOM_LDS - 1 ? 1.f : 0.f);
         }
     }
-    double* mb = mom + (long long)b * NMOM;
+    __syncthreads();
+    const int mi = threadIdx.x % NMOM, sub = threadIdx.x / NMOM;      // 3 x 65 = 195 working threads
+    if (sub < 3) {
+        int ja = mi, jb = -1;
+        if (mi >= K0) {                     // pair index p -> (j, i), rows of lengths 10, 9, ..., 1
+            int p = mi - K0, j = 0;
+            while (p >= K0 - j) { p -= K0 - j; ++j; }
+            ja = j, jb = j + p;
+        }
+        // first moments multiply by the constant 1 (stride 0): one code path, no branch in the loop; positions past
+        // the chunk read zeros.  Runs of 8 positions are summed in fp32 (8 independent LDS reads in flight), the runs
+        // in double.
+        const float* pa = sx + ja;
+        const float* pb = jb < 0 ? sx + MOM_LDS - 1 : sx + jb;
+        const int sb = jb < 0 ? 0 : ST0;
+        double acc = 0.0;
+        const int n = t1 - t0;
+        for (int t = sub; t < n; t += 24) {
+            float run = 0.f;
 #pragma unroll
-    for (int j = 0; j < K0; ++j) {
-        const double v = wave_sum_d((double)s1[j]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&mb[j], v);
+            for (int u = 0; u < 8; ++u)       // a select, not a branch: positions past the chunk contribute nothing
+                run = fmaf(t + 3 * u < n ? pa[(t + 3 * u) * ST0] : 0.f, pb[(t + 3 * u) * sb], run);
+            acc += (double)run;
+        }
+        part[sub][mi] = acc;
     }
-#pragma unroll
-    for (int j = 0; j < 55; ++j) {
-        const double v = wave_sum_d((double)s2[j]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&mb[K0 + j], v);
-    }
+    __syncthreads();
+    // one slot per (clip, chunk): no atomics, no zeroing; conv0_finalize_kernel adds the chunks in a fixed order
+    if (threadIdx.x < NMOM)
+        mom[((long long)b * gridDim.x + blockIdx.x) * NMOM + threadIdx.x] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x];
 }
-
-__global__ void conv0_finalize_kernel(const double* __restrict__ mom, const float* __restrict__ w0,
+__global__ void conv0_finalize_kernel(const double* __restrict__ mom, int nchunks, const float* __restrict__ w0,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, int T0,
                                       float eps, float* __restrict__ ss) {
+    __shared__ double mb[NMOM];
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < NMOM) {            // the clip's moments = sum over its chunks, in chunk order
+        double a = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < nchunks; ++k) a += mom[((long long)b * nchunks + k) * NMOM + threadIdx.x];
+        mb[threadIdx.x] = a;
+    }
+    __syncthreads();
     if (c >= C0) return;
-    const double* mb = mom + (long long)b * NMOM;
     double w[K0];
 #pragma unroll
     for (int j = 0; j < K0; ++j) w[j] = (double)w0[c * K0 + j];
@@ -523,7 +581,7 @@ extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, 
     if (!pcm || !out || !stats || B <= 0 || N <= 0) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     zero_doubles(stats, 2 * B, s);
-    dim3 sgrid(grid_for(N, 256, 8), B);      // 8 workgroups per clip: 16 atomics per clip
+    dim3 sgrid(grid_for(N / 8, 256, 32), B); // up to 32 workgroups per clip (16-byte loads): 64 atomics per clip
     dim3 grid(grid_for(N, 256, 64), B);
     if (is_int16) {
         hipLaunchKernelGGL(audio_stats_kernel<true>, sgrid, dim3(256), 0, s, pcm, N, joint, stats);
@@ -542,10 +600,10 @@ static int conv0_impl(const float* x, int B, int N, const float* w0, const float
     if ((y_hi == nullptr) != (y_lo == nullptr)) return AVI_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int T0 = (N - K0) / ST0 + 1;
-    zero_doubles(moments, NMOM * B, s);
-    hipLaunchKernelGGL(conv0_moments_kernel, dim3(grid_for(T0, 256, 32), B), dim3(256), 0, s, x, N, T0, moments);
-    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, w0, gamma, beta, T0, eps,
-                       scale_shift);
+    const int nchunks = (T0 + MOM_CH - 1) / MOM_CH;
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3(nchunks, B), dim3(256), 0, s, x, N, T0, moments);
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, nchunks, w0, gamma, beta, T0,
+                       eps, scale_shift);
     hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + C0_TT - 1) / C0_TT, B), dim3(256), 0, s, x, N, T0, w0,
                        scale_shift, y, y_hi, y_lo, fmt);
     return avi_launch_status();

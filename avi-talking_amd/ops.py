@@ -166,7 +166,7 @@ def conv0_gn_gelu(x, w0, gamma, beta, eps=1e-5, out=None):
     T0 = (N - 10) // 5 + 1
     if out is None:
         out = torch.empty((B, T0, 512), dtype=torch.float32, device=x.device)
-    mom = torch.empty((65 * B,), dtype=torch.float64, device=x.device)
+    mom = torch.empty((65 * B * ((T0 + 511) // 512),), dtype=torch.float64, device=x.device)
     ss = torch.empty((1024 * B,), dtype=torch.float32, device=x.device)
     L.check(L.load().avi_conv0_gn_gelu(x.data_ptr(), B, N, _f32c(w0, "w0").data_ptr(), gamma.data_ptr(),
                                        beta.data_ptr(), eps, out.data_ptr(), mom.data_ptr(), ss.data_ptr(),
@@ -350,7 +350,7 @@ def conv0_gn_gelu_planes(x, w0, gamma, beta, eps=1e-5, fmt=PLANES_BF16):
     B, N = x.shape
     T0 = (N - 10) // 5 + 1
     out = Planes((B, T0, 512), x.device, fmt)
-    mom = torch.empty((65 * B,), dtype=torch.float64, device=x.device)
+    mom = torch.empty((65 * B * ((T0 + 511) // 512),), dtype=torch.float64, device=x.device)
     ss = torch.empty((1024 * B,), dtype=torch.float32, device=x.device)
     L.check(L.load().avi_conv0_gn_gelu_planes(x.data_ptr(), B, N, _f32c(w0, "w0").data_ptr(), gamma.data_ptr(),
                                               beta.data_ptr(), eps, out.hi.data_ptr(), out.lo.data_ptr(), mom.data_ptr(),

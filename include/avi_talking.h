@@ -103,7 +103,7 @@ int avi_pack_weight_split(const float* W, int N, int K, int N_pad, uint16_t* hi,
 int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, int joint, float eps,
                         float* out, double* stats, void* stream);
 /* x [B][N] -> y [B][T0][512] = GELU(GroupNorm_512(Conv1d(1,512,10,stride 5)(x))), T0 = (N-10)/5+1.
- * w0 [512][10], gamma/beta [512]; moments: scratch >= 65*B doubles; scale_shift: scratch >= 1024*B floats. */
+ * w0 [512][10], gamma/beta [512]; moments: scratch >= 65*B*ceil(T0/512) doubles, T0 = (N-10)/5+1 (per-chunk partial moments, no zeroing needed); scale_shift: scratch >= 1024*B floats. */
 int avi_conv0_gn_gelu(const float* x, int B, int N, const float* w0, const float* gamma, const float* beta,
                       float eps, float* y, double* moments, float* scale_shift, void* stream);
 /* same, result as hi/lo planes [B][T0][512] (the A operand format of the LDS-DMA GEMM; plane_fmt = AVI_PLANES_*) */

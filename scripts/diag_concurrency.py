@@ -42,7 +42,7 @@ xin = torch.ones(32, 4096, device=dev)
 parts = torch.empty((16, 32, 4096), device=dev)
 x = ops.audio_normalize(pcm, joint=False)
 y = torch.empty((B, T0, 512), dtype=torch.float32, device=dev)
-mom = torch.empty((65 * B,), dtype=torch.float64, device=dev)
+mom = torch.empty((65 * B * ((T0 + 511) // 512),), dtype=torch.float64, device=dev)   # per-chunk partial moments
 ss = torch.empty((1024 * B,), dtype=torch.float32, device=dev)
 side = pipe.side if os.environ.get('PRIO', '-1') == '-1' else torch.cuda.Stream(device=dev, priority=int(os.environ['PRIO']))
 print('side stream priority', side.priority)
