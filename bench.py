@@ -288,7 +288,7 @@ def main():
     side = pipe.side          # a second pipeline of this process keeps the high-priority stream the first one used
     del pipe, out
     torch.cuda.empty_cache()
-    if args.prec == "bf16x3" and not args.no_train:
+    if args.prec == "bf16x3" and not args.no_train and world == 1:      # N = 1 only, like the CPU baseline
         run_leg("f16x2_opt_in", lambda: measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args, side))
         torch.cuda.empty_cache()
     if not args.no_train:

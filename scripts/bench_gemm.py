@@ -37,7 +37,7 @@ for name, batch, M, N, K, lda in shapes:
             Ch = torch.empty(batch, M, N, dtype=torch.int16, device=dev); Cl = torch.empty_like(Ch)
             def run():
                 ops.gemm_raw(Ahi=Ah.data_ptr(), Alo=Al.data_ptr(), lda=lda, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
-                             Chi=Ch.data_ptr(), Clo=Cl.data_ptr(), ldc=N, M=M, N=N, K=K, act=ops.ACT_GELU, prec=prec,
+                             Chi=Ch.data_ptr(), Clo=Cl.data_ptr(), ldc=N, M=M, N=N, K=K, act=int(os.environ.get('GEMM_ACT', ops.ACT_GELU)), prec=prec,
                              batch=batch, sA=(rows, 0), sC=(M * N, 0))
         for _ in range(3): run()
         torch.cuda.synchronize(); t = time.time()
