@@ -166,3 +166,42 @@ class SamplingPipeline:
             self._e_taken.record(self._s_head)
             self._g_head.replay()
         return self._pout
+
+    # ---- utterances of different lengths (the reference's loop takes them one at a time: train_diffusion_prior.py:689-771)
+    def run_many(self, pcm_list, voxels, noises=None, generator=None, max_batch=32):
+        """Ragged input: ``pcm_list`` holds one 1-D int16/fp32 tensor per utterance (any lengths), ``voxels`` (n, 768) the
+        caption features, ``noises`` (T_d+1, n, 1, 128) the DDPM noise per utterance (drawn from ``generator`` in the
+        reference's call order when None).  Utterances of equal frame count are batched (per-clip audio statistics make
+        the result independent of the grouping); audio beyond the last whole 640-sample frame is dropped as in
+        ``process_audio`` (evaluation_functions.py:699-714).  Returns a list of dicts in input order; an utterance shorter
+        than one frame yields empty (0, 50) / (0, 3) coefficient arrays (the reference's sample would hold zero frames)."""
+        n = len(pcm_list)
+        if voxels.shape[0] != n:
+            raise ValueError("one caption feature per utterance")
+        if n == 0:
+            return []
+        if self.talking_head.joint_norm:
+            raise ValueError("run_many needs per-clip audio statistics (joint_norm=False)")
+        if noises is None:
+            noises = torch.stack([self.prior.draw_noise(1, generator)[:, 0] for _ in range(n)], 1)
+        frames = [int(p.numel()) // 640 for p in pcm_list]
+        out = [None] * n
+        groups = {}
+        for i, t in enumerate(frames):
+            groups.setdefault(t, []).append(i)
+        for t, idx in sorted(groups.items()):
+            if t == 0:
+                for i in idx:
+                    z = lambda c: torch.zeros((0, c), dtype=torch.float32, device=self.device)
+                    out[i] = {"predicted_exp": z(50), "predicted_jaw": z(3), "style_emb": None}
+                continue
+            for k in range(0, len(idx), max_batch):
+                sel = idx[k:k + max_batch]
+                pcm = torch.stack([pcm_list[i].reshape(-1)[:t * 640].to(self.device) for i in sel], 0).contiguous()
+                sel_t = torch.as_tensor(sel, device=noises.device)
+                res = self.run(pcm, voxels[sel].to(self.device).contiguous(),
+                               noises.index_select(1, sel_t).to(self.device).contiguous())
+                for j, i in enumerate(sel):
+                    out[i] = {"predicted_exp": res["predicted_exp"][j], "predicted_jaw": res["predicted_jaw"][j],
+                              "style_emb": res["style_emb"][j]}
+        return out

@@ -125,3 +125,27 @@ def test_two_term_fp16_pipeline_coefficients(gpu):
             (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
     print(f"f16x2 pipeline: max-abs coefficient err {e:.2e}")
     assert e < 1e-3
+
+
+def test_ragged_and_empty_utterances(gpu):
+    """run_many: utterances of different lengths (incl. a trailing partial frame, two of equal length, one shorter than a
+    frame) and the empty list; every result equals the single-utterance run, whatever it was batched with."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu)
+    assert pipe.run_many([], torch.zeros(0, 768)) == []
+    g = torch.Generator().manual_seed(5)
+    lens = [640 * 12 + 100, 640 * 30, 300, 640 * 12 + 639, 640 * 9]
+    pcms = [(torch.randn(n, generator=g) * 3000).to(torch.int16) for n in lens]
+    voxels = torch.randn(len(lens), 768, generator=g)
+    noises = torch.randn(101, len(lens), 1, 128, generator=g)
+    outs = pipe.run_many(pcms, voxels, noises)
+    assert [o["predicted_exp"].shape[0] for o in outs] == [12, 30, 0, 12, 9]
+    assert outs[2]["predicted_jaw"].shape == (0, 3)
+    for i in (0, 1, 3, 4):
+        T = lens[i] // 640
+        one = pipe.run(pcms[i][:T * 640][None].to(gpu), voxels[i:i + 1].to(gpu), noises[:, i:i + 1].to(gpu))
+        assert (outs[i]["predicted_exp"] - one["predicted_exp"][0]).abs().max().item() < 1e-5
+        assert (outs[i]["predicted_jaw"] - one["predicted_jaw"][0]).abs().max().item() < 1e-5
+    with pytest.raises(ValueError):
+        pipe.run_many(pcms, voxels[:2], noises)
