@@ -528,6 +528,10 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         hit = busy.get(name) or next((v for k, v in busy.items() if k.startswith(base) and (tag in k if tag else True)), None)
         return hit["mfma_busy_frac"] if hit else None
 
+    _B = voxel.shape[0]
+    _spg = max(1, min(prior.samples_per_group, _B)) if prior.samples_per_group > 0 else 1
+    sampler_cus = -(-_B // _spg)
+
     def describe(name):
         ms, fl, n = fam[name]
         ach = fl / (ms * 1e-3) / 1e12
@@ -540,6 +544,9 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         return {"bound": "mfma", "kernel": f"{name} (bf16 MFMA 16x16x32, {ns} MFMA per product)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),
+                # inside the pass the sampler's workgroups hold `sampler_cus` of the 256 CUs: the same rate against the
+                # matrix-core peak of the CUs the GEMMs can actually run on
+                "mfma_issued_frac_of_free_cus": round(ach * ns / (PEAK_BF16_TFLOPS * (256 - sampler_cus) / 256.0), 4),
                 "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "ms_per_step": round(ms / reps, 3), "frac_of_step": round(ms / reps / step_ms, 3),
                 "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
