@@ -177,6 +177,305 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
     Lin<DIM, DIM>::run(a.p.proj_hi, a.p.proj_lo, ring, s, d.po + row0 * DIM, R);
 }
 
+// ============================================================================================== fused backward
+// The dX chain of the six layers in ONE launch: from the gradient at the output of the last layer down to the gradient of
+// the token rows, storing the output gradient of every matrix (the deferred dW launches read them), per-workgroup
+// partial LayerNorm-gain gradients (reduced by one small launch: deterministic) and adding the null-kv / relative-bias
+// gradients with atomics as the stand-alone attention backward does.  Linears run on the TRANSPOSED fragment-major
+// planes (dX = dY . W = Lin over W^T).
+constexpr int XSB = 1028, YSB = 516;
+struct AttnB {
+    float qn[8][3][64], kn[4][64], vv[4][64], qinv[8][3], kinv[4], p[8][3][4], ds[8][3][4], dkn[4][64];
+};
+struct SmemB {
+    float tok[MR][DIM];     // gradient on the residual stream
+    float tmid[MR][DIM];    // gradient at the middle of the layer (after attention, before the feed-forward)
+    float x[MR][XSB];
+    float y[MR][YSB];
+    float gain[AVI_PRIOR_MAX_DEPTH][3][DIM];
+    float relb[96];
+    float dgw[8][2 * DIM];  // per-wave LayerNorm-gain partials (two LayerNorms handled in one phase)
+    AttnB at[2];
+};
+
+struct TrainBwdArgs {
+    AviPriorWeights w;
+    AviPriorPlanes p;       // planes of the TRANSPOSED matrices
+    AviPriorTrainBwd d;
+};
+__device__ __forceinline__ const TrainBwdArgs& bargs() { return *(const TrainBwdArgs*)__builtin_amdgcn_kernarg_segment_ptr(); }
+
+// LayerNorm backward of one 128-wide row held as (a, b) = columns (lane, lane + 64): returns dx in (da, db) and adds
+// dy * xhat to the wave's gain-gradient partial.  dalle2 LayerNorm: y = (x - mean) rsqrt(var + 1e-5) g.
+__device__ __forceinline__ void ln_bwd_row(float xa, float xb, float& da, float& db, const float* g, int lane, float* dg) {
+    const float mean = wave_sum_u(xa + xb) * (1.f / DIM);
+    const float ca = xa - mean, cb = xb - mean;
+    const float rstd = rsqrtf(wave_sum_u(ca * ca + cb * cb) * (1.f / DIM) + 1e-5f);
+    const float ha = ca * rstd, hb = cb * rstd;
+    dg[lane] += da * ha;
+    dg[lane + 64] += db * hb;
+    const float ta = da * g[lane], tb = db * g[lane + 64];
+    const float sa = wave_sum_u(ta + tb) * (1.f / DIM), sb = wave_sum_u(ta * ha + tb * hb) * (1.f / DIM);
+    da = rstd * (ta - sa - ha * sb);
+    db = rstd * (tb - sa - hb * sb);
+}
+
+// prior_attn_bwd_kernel (train.hip) for ONE sample on 256 threads t = 0..255 of a 512-thread workgroup (the two halves
+// work on two samples at once; every barrier is reached by both).  qkvb: the sample's raw projections [3][640] (global),
+// dout(i, c): gradient of the attention output, row i (LDS), dq(i, c): where the projection gradients go (LDS).
+template <class DOUT, class DQ>
+__device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* __restrict__ qkvb, const float* __restrict__ null_kv,
+                                                const float* relb, const float* __restrict__ rot_cos,
+                                                const float* __restrict__ rot_sin, DOUT dout, DQ dq, float* __restrict__ dnull_kv,
+                                                float* __restrict__ drel, AttnB& c) {
+    const int lane = t & 63, wave = t >> 6;
+    if (live) {
+        for (int vix = wave; vix < 28; vix += 4) {
+            float x;
+            int pos = -1;
+            if (vix < 24) {
+                const int h = vix / 3, i = vix - h * 3;
+                x = qkvb[i * 640 + h * 64 + lane] * 16.0f;
+                pos = i;
+            } else if (vix < 27) {
+                const int i = vix - 24;
+                x = qkvb[i * 640 + 512 + lane];
+                pos = i;
+                c.vv[1 + i][lane] = qkvb[i * 640 + 576 + lane];
+            } else {
+                x = null_kv[lane];
+                c.vv[0][lane] = null_kv[64 + lane];
+            }
+            const float partner = __shfl_xor(x, 1, 64);
+            if (pos >= 0 && lane < 32) {
+                const float cs = rot_cos[pos * 32 + lane], sn = rot_sin[pos * 32 + lane];
+                x = x * cs + ((lane & 1) ? partner : -partner) * sn;
+            }
+            const float inv = 1.f / fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);
+            if (vix < 24) {
+                const int h = vix / 3, i = vix - h * 3;
+                c.qn[h][i][lane] = x * inv * 4.0f;
+                if (lane == 0) c.qinv[h][i] = inv;
+            } else {
+                c.kn[vix == 27 ? 0 : vix - 23][lane] = x * inv * 4.0f;
+                if (lane == 0) c.kinv[vix == 27 ? 0 : vix - 23] = inv;
+            }
+        }
+    }
+    __syncthreads();
+    if (live && t < 96) {
+        const int h = t / 12, r = t - h * 12, i = r >> 2, j = r & 3;
+        float a = 0.f, dp = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < 64; ++d) {
+            a = fmaf(c.qn[h][i][d], c.kn[j][d], a);
+            dp = fmaf(dout(i, h * 64 + d), c.vv[j][d], dp);
+        }
+        c.p[h][i][j] = a + relb[(h * 3 + i) * 4 + j];
+        c.ds[h][i][j] = dp;
+    }
+    __syncthreads();
+    if (live && t < 24) {
+        float* r = &c.p[0][0][0] + t * 4;
+        const float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+        const float e0 = __expf(r[0] - mx), e1 = __expf(r[1] - mx), e2 = __expf(r[2] - mx), e3 = __expf(r[3] - mx);
+        const float inv = 1.f / (e0 + e1 + e2 + e3);
+        r[0] = e0 * inv; r[1] = e1 * inv; r[2] = e2 * inv; r[3] = e3 * inv;
+        float* dpr = &c.ds[0][0][0] + t * 4;
+        const float dot = dpr[0] * r[0] + dpr[1] * r[1] + dpr[2] * r[2] + dpr[3] * r[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dpr[j] = r[j] * (dpr[j] - dot);
+    }
+    __syncthreads();
+    if (live) {
+        if (t < 96) atomicAdd(&drel[t], (&c.ds[0][0][0])[t]);
+        const int j = wave, d = lane;
+        float a = 0.f, kk = 0.f;
+        for (int h = 0; h < 8; ++h)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a = fmaf(c.p[h][i][j], dout(i, h * 64 + d), a);
+                kk = fmaf(c.ds[h][i][j], c.qn[h][i][d], kk);
+            }
+        if (j == 0) atomicAdd(&dnull_kv[64 + d], a);
+        else dq(j - 1, 576 + d, a);
+        c.dkn[j][d] = kk;
+    }
+    __syncthreads();
+    if (live) {
+        for (int vix = wave; vix < 28; vix += 4) {
+            float dy, y, inv;
+            int pos = -1;
+            if (vix < 24) {
+                const int h = vix / 3, i = vix - h * 3;
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = fmaf(c.ds[h][i][j], c.kn[j][lane], a);
+                dy = a; y = c.qn[h][i][lane]; inv = c.qinv[h][i]; pos = i;
+            } else {
+                const int j = vix == 27 ? 0 : vix - 23;
+                dy = c.dkn[j][lane]; y = c.kn[j][lane]; inv = c.kinv[j]; pos = vix == 27 ? -1 : vix - 24;
+            }
+            const float ydy = wave_sum(y * dy);
+            float dx = inv * (4.0f * dy - y * ydy * 0.25f);
+            if (pos >= 0) {
+                const float partner = __shfl_xor(dx, 1, 64);
+                if (lane < 32) {
+                    const float cs = rot_cos[pos * 32 + lane], sn = rot_sin[pos * 32 + lane];
+                    dx = dx * cs + ((lane & 1) ? -partner : partner) * sn;
+                }
+            }
+            if (vix < 24) {
+                const int h = vix / 3, i = vix - h * 3;
+                dq(i, h * 64 + lane, dx * 16.0f);
+            } else if (vix < 27) {
+                dq(vix - 24, 512 + lane, dx);
+            } else {
+                atomicAdd(&dnull_kv[lane], dx);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdArgs args_by_value, int B, int S) {
+    const TrainBwdArgs& a = bargs();
+    const AviPriorWeights& w = a.w;
+    const AviPriorTrainBwd& d = a.d;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SmemB& s = *reinterpret_cast<SmemB*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * S;
+    const int Sg = min(S, B - b0), R = 3 * Sg;
+    const long long row0 = 3LL * b0, RT = 3LL * B;
+    for (int i = tid; i < MR * XSB; i += NT) (&s.x[0][0])[i] = 0.f;
+    for (int i = tid; i < MR * DIM; i += NT) {
+        (&s.tok[0][0])[i] = 0.f;
+        (&s.tmid[0][0])[i] = 0.f;
+    }
+    for (int i = tid; i < w.depth * 3 * DIM; i += NT) {
+        const int l = i / (3 * DIM), r = i - l * 3 * DIM, k = r / DIM, dd = r - k * DIM;
+        const AviPriorLayer& L = w.layer[l];
+        s.gain[l][k][dd] = (k == 0 ? L.norm_g : k == 1 ? L.out_g : L.ff_g)[dd];
+    }
+    for (int i = tid; i < 96; i += NT) s.relb[i] = w.rel_bias[i];
+    __syncthreads();
+    for (int i = tid; i < R * DIM; i += NT) s.tok[i / DIM][i % DIM] = d.dtok_top[(row0 + i / DIM) * DIM + i % DIM];
+    __syncthreads();
+    WRing ring;
+    float* dgp = d.dgamma_part + (long long)blockIdx.x * w.depth * 3 * DIM;
+    for (int l = w.depth - 1; l >= 0; --l) {
+        const AviPriorLayerPlanes& P = a.p.layer[l];
+        Lin<DIM, FFI>::prefetch(P.w2_hi, P.w2_lo, ring);
+        // ---- dy of linear2 = the gradient arriving at the layer; its rows are the input of dX = dY . W2
+        for (int i = tid; i < R * DIM; i += NT) {
+            const int r = i / DIM, c = i - r * DIM;
+            const float v = s.tok[r][c];
+            s.x[r][c] = v;
+            d.dy_w2[((long long)l * RT + row0 + r) * DIM + c] = v;
+        }
+        __syncthreads();
+        Lin<DIM, FFI>::run(P.w2_hi, P.w2_lo, ring, s);                       // dsw [R][512]
+        __syncthreads();
+        Lin<2 * FFI, DIM>::prefetch(P.w1_hi, P.w1_lo, ring);
+        // ---- SwiGLU backward: hff = (value | gate) from the forward dump
+        for (int o = tid; o < R * FFI; o += NT) {
+            const int m = o / FFI, c = o - m * FFI;
+            const float* hr = d.hff + ((long long)l * RT + row0 + m) * 2 * FFI;
+            const float av = hr[c], g = hr[FFI + c], dy = s.y[m][c];
+            const float sg = 1.f / (1.f + __expf(-g));
+            const float da = dy * g * sg, dgt = dy * av * sg * (1.f + g * (1.f - sg));
+            s.x[m][c] = da;
+            s.x[m][FFI + c] = dgt;
+            float* o1 = d.dy_w1 + ((long long)l * RT + row0 + m) * 2 * FFI;
+            o1[c] = da;
+            o1[FFI + c] = dgt;
+        }
+        __syncthreads();
+        Lin<2 * FFI, DIM>::run(P.w1_hi, P.w1_lo, ring, s);                   // dn2 [R][128]
+        __syncthreads();
+        Lin<DIM, INNER>::prefetch(P.out_hi, P.out_lo, ring);
+        // ---- LayerNorm (ff 0.g) backward on tokm, + residual -> dtokm; LayerNorm (to_out.1.g) backward on o1 -> do1
+        {
+            float* dg = s.dgw[wave];
+            dg[lane] = dg[lane + 64] = dg[DIM + lane] = dg[DIM + lane + 64] = 0.f;
+            for (int r = wave; r < R; r += 8) {
+                const float* tm = d.tokm + ((long long)l * RT + row0 + r) * DIM;
+                float da = s.y[r][lane], db = s.y[r][lane + 64];
+                ln_bwd_row(tm[lane], tm[lane + 64], da, db, s.gain[l][2], lane, dg);
+                da += s.tok[r][lane];
+                db += s.tok[r][lane + 64];
+                s.tmid[r][lane] = da;
+                s.tmid[r][lane + 64] = db;
+                const float* o1 = d.o1 + ((long long)l * RT + row0 + r) * DIM;
+                ln_bwd_row(o1[lane], o1[lane + 64], da, db, s.gain[l][1], lane, dg + DIM);
+                s.x[r][lane] = da;
+                s.x[r][lane + 64] = db;
+                float* dyo = d.dy_out + ((long long)l * RT + row0 + r) * DIM;
+                dyo[lane] = da;
+                dyo[lane + 64] = db;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * DIM) {                       // gain gradients of this workgroup: ff 0.g (slot 2), to_out.1.g (slot 1)
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += s.dgw[wv][tid];
+            dgp[(l * 3 + (tid < DIM ? 2 : 1)) * DIM + (tid & (DIM - 1))] = v;
+        }
+        Lin<DIM, INNER>::run(P.out_hi, P.out_lo, ring, s);                   // dao [R][512]
+        __syncthreads();
+        Lin<NQKV, DIM>::prefetch(P.qkv_hi, P.qkv_lo, ring);
+        // ---- attention backward, two samples at a time (threads 0..255 / 256..511)
+        for (int sm0 = 0; sm0 < Sg; sm0 += 2) {
+            const int half = tid >> 8, sm = sm0 + half;
+            const bool live = sm < Sg;
+            const int rb = 3 * (live ? sm : 0);
+            const float* qkvb = d.qkv + ((long long)l * RT + row0 + rb) * NQKV;
+            float* dyq = d.dy_qkv + ((long long)l * RT + row0 + rb) * NQKV;
+            auto dout = [&](int i, int c) { return s.y[rb + i][c]; };
+            auto dq = [&](int i, int c, float v) {
+                s.x[rb + i][c] = v;
+                dyq[i * NQKV + c] = v;
+            };
+            attn_bwd_sample(tid & 255, live, qkvb, w.layer[l].null_kv, s.relb, w.rot_cos, w.rot_sin, dout, dq,
+                            d.dnull_kv[l], d.drel, s.at[half]);
+        }
+        Lin<NQKV, DIM>::run(P.qkv_hi, P.qkv_lo, ring, s);                    // dn1 [R][128]
+        __syncthreads();
+        // ---- LayerNorm (norm.g) backward on the layer's input, + dtokm -> gradient leaving the layer
+        {
+            float* dg = s.dgw[wave];
+            dg[lane] = dg[lane + 64] = 0.f;
+            for (int r = wave; r < R; r += 8) {
+                const float* ti = d.tok_in + ((long long)l * RT + row0 + r) * DIM;
+                float da = s.y[r][lane], db = s.y[r][lane + 64];
+                ln_bwd_row(ti[lane], ti[lane + 64], da, db, s.gain[l][0], lane, dg);
+                s.tok[r][lane] = da + s.tmid[r][lane];
+                s.tok[r][lane + 64] = db + s.tmid[r][lane + 64];
+            }
+        }
+        __syncthreads();
+        if (tid < DIM) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += s.dgw[wv][tid];
+            dgp[(l * 3 + 0) * DIM + tid] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < R * DIM; i += NT) d.dtok0[(row0 + i / DIM) * DIM + i % DIM] = s.tok[i / DIM][i % DIM];
+}
+
+// gain gradient = sum of the workgroups' partials, in workgroup order: grid (depth * 3), 128 threads
+__global__ __launch_bounds__(128) void prior_gain_grad_kernel(const float* __restrict__ part, int groups, int depth,
+                                                               AviPriorGainGrads out) {
+    const int li = blockIdx.x, l = li / 3, k = li - 3 * l, c = threadIdx.x;
+    float v = 0.f;
+    for (int g = 0; g < groups; ++g) v += part[((long long)g * depth * 3 + li) * DIM + c];
+    out.g[l][k][c] = v;
+}
+
 // dst plane in fragment-major order [N/16][K/32][64 lanes][8] from a row-major [N][K] plane (or, transpose != 0, from the
 // row-major [K][N] plane of the transposed matrix): one thread = one lane slot of 8 values
 __global__ __launch_bounds__(256) void pack_fragment_planes_kernel(const AviPlaneJob* __restrict__ jobs, int njobs) {
@@ -246,5 +545,33 @@ extern "C" int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorP
     const int groups = (B + samples_per_group - 1) / samples_per_group;
     hipLaunchKernelGGL(prior_train_fwd_kernel, dim3(groups), dim3(NT), sizeof(Smem), static_cast<hipStream_t>(stream), args,
                        B, samples_per_group);
+    return avi_launch_status();
+}
+
+extern "C" int avi_prior_train_backward(const AviPriorWeights* w, const AviPriorPlanes* pT, const AviPriorTrainBwd* d,
+                                        const AviPriorGainGrads* gains, int B, int samples_per_group, void* stream) {
+    if (!w || !pT || !d || !gains || B <= 0 || samples_per_group < 1 || samples_per_group > SMAX) return AVI_EINVAL;
+    if (w->depth < 1 || w->depth > AVI_PRIOR_MAX_DEPTH || !w->rel_bias || !w->rot_cos || !w->rot_sin) return AVI_EINVAL;
+    for (int l = 0; l < w->depth; ++l) {
+        const AviPriorLayerPlanes& P = pT->layer[l];
+        const AviPriorLayer& L = w->layer[l];
+        if (!P.qkv_hi || !P.qkv_lo || !P.out_hi || !P.out_lo || !P.w1_hi || !P.w1_lo || !P.w2_hi || !P.w2_lo) return AVI_EINVAL;
+        if (!L.norm_g || !L.out_g || !L.ff_g || !L.null_kv || !d->dnull_kv[l]) return AVI_EINVAL;
+        for (int k = 0; k < 3; ++k)
+            if (!gains->g[l][k]) return AVI_EINVAL;
+    }
+    if (!d->dtok_top || !d->tok_in || !d->qkv || !d->o1 || !d->tokm || !d->hff || !d->dy_w2 || !d->dy_w1 || !d->dy_out ||
+        !d->dy_qkv || !d->dtok0 || !d->dgamma_part || !d->drel)
+        return AVI_EINVAL;
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(prior_train_bwd_kernel), (int)sizeof(SmemB));
+    TrainBwdArgs args;
+    args.w = *w;
+    args.p = *pT;
+    args.d = *d;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int groups = (B + samples_per_group - 1) / samples_per_group;
+    hipLaunchKernelGGL(prior_train_bwd_kernel, dim3(groups), dim3(NT), sizeof(SmemB), s, args, B, samples_per_group);
+    hipLaunchKernelGGL(prior_gain_grad_kernel, dim3(w->depth * 3), dim3(128), 0, s, d->dgamma_part, groups, w->depth, *gains);
     return avi_launch_status();
 }

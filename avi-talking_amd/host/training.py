@@ -344,6 +344,9 @@ class PriorTrainer:
         # AVI_TRAIN_FUSED_FWD=0: the forward of the denoiser as the chain of ~55 launches it used to be (A/B switch, tests)
         self.fused_forward = os.environ.get("AVI_TRAIN_FUSED_FWD", "1") == "1"
         self.fwd_samples_per_group = int(os.environ.get("AVI_TRAIN_FWD_SPG", "2"))   # 32 workgroups at B = 64
+        # AVI_TRAIN_FUSED_BWD=0: the dX chain of the denoiser's backward as ~90 launches (needs the fused forward's dumps)
+        self.fused_backward = self.fused_forward and os.environ.get("AVI_TRAIN_FUSED_BWD", "1") == "1"
+        self.bwd_samples_per_group = int(os.environ.get("AVI_TRAIN_BWD_SPG", "2"))
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
@@ -432,6 +435,55 @@ class PriorTrainer:
             ly.norm_g, ly.null_kv, ly.out_g, ly.ff_g = S.ptr(a + "norm.g"), S.ptr(a + "null_kv"), S.ptr(a + "to_out.1.g"), S.ptr(f + "0.g")
         cw.final_g = S.ptr(c + "norm.g")
         self._fplanes_struct, self._fweights = pl, cw
+        # the same matrices TRANSPOSED (dX = dY . W runs the linear over W^T), for the one-launch backward
+        tjobs = (L.AviPlaneJob * (4 * self.depth))()
+        self._tplanes = []
+        ttotal = 0
+        for jb, (name, N, K) in zip(tjobs, mats[:-1]):
+            hi = torch.empty(N * K, dtype=torch.int16, device=dev)
+            lo = torch.empty_like(hi)
+            self._tplanes.append((hi, lo))
+            jb.src_hi, jb.src_lo, jb.dst_hi, jb.dst_lo = S.hi_ptr(name), S.lo_ptr(name), hi.data_ptr(), lo.data_ptr()
+            jb.N, jb.K, jb.first_block, jb.transpose = K, N, ttotal, 1        # the packed matrix is W^T: [K_w][N_w]
+            ttotal += jb.blocks()
+        self._tjobs = (torch.frombuffer(bytearray(bytes(tjobs)), dtype=torch.uint8).to(dev), 4 * self.depth, ttotal)
+        pt = L.AviPriorPlanes()
+        for l in range(self.depth):
+            lp = pt.layer[l]
+            (lp.qkv_hi, lp.qkv_lo), (lp.out_hi, lp.out_lo), (lp.w1_hi, lp.w1_lo), (lp.w2_hi, lp.w2_lo) = [
+                (h.data_ptr(), o.data_ptr()) for h, o in self._tplanes[4 * l:4 * l + 4]]
+        self._tplanes_struct = pt
+        gg = L.AviPriorGainGrads()
+        for l in range(self.depth):
+            a, f = c + f"layers.{l}.0.", c + f"layers.{l}.1."
+            gg.g[l][0], gg.g[l][1], gg.g[l][2] = S.gptr(a + "norm.g"), S.gptr(a + "to_out.1.g"), S.gptr(f + "0.g")
+        self._gain_grads = gg
+
+    def _fused_backward(self, ws, dtok, B, drel):
+        """The dX chain of the six layers in one launch (+ the gain-gradient reduction): fills the stacked dy buffers the
+        deferred dW launches read, returns the gradient of the token rows."""
+        import ctypes as C
+        so = L.load()
+        S, R = self.store, 3 * B
+        raw, n, total = self._tjobs
+        L.check(so.avi_pack_fragment_planes(raw.data_ptr(), n, total, L.stream_ptr()), "avi_pack_fragment_planes")
+        fw = ws["fwd"]
+        groups = -(-B // self.bwd_samples_per_group)
+        part = fw.get("dgamma_part")
+        if part is None or part.numel() < groups * self.depth * 3 * DIM:
+            part = fw["dgamma_part"] = torch.empty(groups * self.depth * 3 * DIM, dtype=torch.float32, device=self.device)
+            fw["dtok0"] = torch.empty((R, DIM), dtype=torch.float32, device=self.device)
+        d = L.AviPriorTrainBwd()
+        d.dtok_top = dtok.data_ptr()
+        d.tok_in, d.qkv, d.o1, d.tokm, d.hff = (fw[k].data_ptr() for k in ("tok_in", "qkv", "o1", "tokm", "hff"))
+        d.dy_w2, d.dy_w1, d.dy_out, d.dy_qkv = (ws[k]["dy"].data_ptr() for k in ("w2", "w1", "out", "qkv"))
+        d.dtok0, d.dgamma_part, d.drel = fw["dtok0"].data_ptr(), part.data_ptr(), drel.data_ptr()
+        for l in range(self.depth):
+            d.dnull_kv[l] = S.gptr(self.c + f"layers.{l}.0.null_kv")
+        L.check(so.avi_prior_train_backward(C.byref(self._fweights), C.byref(self._tplanes_struct), C.byref(d),
+                                            C.byref(self._gain_grads), B, self.bwd_samples_per_group, L.stream_ptr()),
+                "avi_prior_train_backward")
+        return fw["dtok0"]
 
     def _fused_forward(self, ws, tok, B, rel_bias):
         """tokens -> all six layers -> project_out in two launches (plane re-pack + avi_prior_train_forward).  Returns
@@ -621,26 +673,30 @@ class PriorTrainer:
         dpo = zbuf[4:4 + R * DIM].view(B, 3, DIM)
         L.check(so.avi_copy_rows(dpred.data_ptr(), DIM, None, dpo.data_ptr() + 2 * DIM * 4, 3 * DIM, B, DIM, st()), "dpo")
         dfin = self.cproj.bwd(fin, dpo.view(R, DIM))
-        # every layer's output gradients land in the stacked workspace (dy of w2 = the gradient arriving at the layer);
-        # only the dX chain runs here, the parameter gradients follow in _deferred_dw
-        dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1, out=ws["w2"]["dy"][self.depth - 1])
         drel = zbuf[4 + R * DIM:4 + R * DIM + 96].view(8, 3, 4)
-        for li, ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(range(self.depth)), reversed(self.layers),
-                                                                   reversed(saved)):
-            a, f = ly["a"], ly["f"]
-            dsw = ly["w2"].bwd_dx(dtok)
-            dhff = ws["w1"]["dy"][li]
-            L.check(so.avi_swiglu_bwd(hff.data_ptr(), dsw.data_ptr(), R, 512, dhff.data_ptr(), st()), "swiglu_bwd")
-            dn2 = ly["w1"].bwd_dx(dhff)
-            dtokm = self._ln_bwd(tokm, dn2, f + "0.g", dx_add=dtok)
-            do1 = self._ln_bwd(o1, dtokm, a + "to_out.1.g", out=ws["out"]["dy"][li])
-            dao = ly["out"].bwd_dx(do1)
-            dqkv = ws["qkv"]["dy"][li]
-            L.check(so.avi_prior_attn_bwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
-                                          self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), dao.data_ptr(), B,
-                                          dqkv.data_ptr(), S.gptr(a + "null_kv"), drel.data_ptr(), st()), "attn_bwd")
-            dn1 = ly["qkv"].bwd_dx(dqkv)
-            dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm, out=ws["w2"]["dy"][li - 1] if li > 0 else None)
+        if self.fused_backward:
+            dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1)
+            dtok = self._fused_backward(ws, dtok, B, drel)
+        else:
+            # every layer's output gradients land in the stacked workspace (dy of w2 = the gradient arriving at the
+            # layer); only the dX chain runs here, the parameter gradients follow in _deferred_dw
+            dtok = self._ln_bwd(tok, dfin, self.c + "norm.g", stable=1, out=ws["w2"]["dy"][self.depth - 1])
+            for li, ly, (tk, n1, qkv, ao, o1, tokm, n2, hff, sw) in zip(reversed(range(self.depth)), reversed(self.layers),
+                                                                       reversed(saved)):
+                a, f = ly["a"], ly["f"]
+                dsw = ly["w2"].bwd_dx(dtok)
+                dhff = ws["w1"]["dy"][li]
+                L.check(so.avi_swiglu_bwd(hff.data_ptr(), dsw.data_ptr(), R, 512, dhff.data_ptr(), st()), "swiglu_bwd")
+                dn2 = ly["w1"].bwd_dx(dhff)
+                dtokm = self._ln_bwd(tokm, dn2, f + "0.g", dx_add=dtok)
+                do1 = self._ln_bwd(o1, dtokm, a + "to_out.1.g", out=ws["out"]["dy"][li])
+                dao = ly["out"].bwd_dx(do1)
+                dqkv = ws["qkv"]["dy"][li]
+                L.check(so.avi_prior_attn_bwd(qkv.data_ptr(), S.ptr(a + "null_kv"), rel_bias.data_ptr(),
+                                              self.rot_cos.data_ptr(), self.rot_sin.data_ptr(), dao.data_ptr(), B,
+                                              dqkv.data_ptr(), S.gptr(a + "null_kv"), drel.data_ptr(), st()), "attn_bwd")
+                dn1 = ly["qkv"].bwd_dx(dqkv)
+                dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm, out=ws["w2"]["dy"][li - 1] if li > 0 else None)
         self._deferred_dw(ws, R)
         # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
         L.check(so.avi_prior_rel_bias(None, None, drel.data_ptr(), S.gptr(rel_name), 8, 3, st()), "rel_bias_bwd")

@@ -87,6 +87,15 @@ class AviPriorTrainDump(C.Structure):
                                    "po")]
 
 
+class AviPriorTrainBwd(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("dtok_top", "tok_in", "qkv", "o1", "tokm", "hff", "dy_w2", "dy_w1", "dy_out", "dy_qkv",
+                                    "dtok0", "dgamma_part")] + [("dnull_kv", _vp * PRIOR_MAX_DEPTH), ("drel", _vp)])
+
+
+class AviPriorGainGrads(C.Structure):
+    _fields_ = [("g", (_vp * 3) * PRIOR_MAX_DEPTH)]
+
+
 class AviPlaneJob(C.Structure):
     _fields_ = [("src_hi", _vp), ("src_lo", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("N", _i), ("K", _i),
                 ("first_block", _i), ("transpose", _i)]
@@ -138,6 +147,7 @@ SIGNATURES = {
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "avi_prior_train_forward": [_vp, _vp, _vp, _i, _i, _vp],
+    "avi_prior_train_backward": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "avi_pack_fragment_planes": [_vp, _i, _i, _vp],
     "avi_zero": [_vp, _ll, _vp],
     "avi_copy_rows": [_vp, _ll, _vp, _vp, _ll, _i, _i, _vp],

@@ -348,6 +348,26 @@ typedef struct AviPriorTrainDump {
 } AviPriorTrainDump;
 int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorPlanes* p, const AviPriorTrainDump* d, int B,
                             int samples_per_group, void* stream);
+/* The dX chain of the backward pass of the same six layers in ONE launch (+ one small launch that reduces the LayerNorm
+ * gain gradients): from `dtok_top`, the gradient at the output of the last layer, to `dtok0`, the gradient of the token
+ * rows.  `pT` holds the fragment-major planes of the TRANSPOSED matrices (avi_pack_fragment_planes, transpose = 1).  The
+ * output gradient of every matrix is stored for the weight-gradient GEMMs (dy_*: [depth][3B][C], C = 128, 1024, 128, 640 for
+ * linear2, linear1, to_out, to_q|to_kv); null_kv and relative-bias gradients are ADDED (atomics) to dnull_kv[l] ([2][64]) and
+ * drel ([8][3][4]); dgamma_part: scratch >= ceil(B / samples_per_group) * depth * 3 * 128 floats. */
+typedef struct AviPriorTrainBwd {
+    const float* dtok_top;
+    const float *tok_in, *qkv, *o1, *tokm, *hff;      /* forward intermediates (AviPriorTrainDump) */
+    float *dy_w2, *dy_w1, *dy_out, *dy_qkv;
+    float* dtok0;
+    float* dgamma_part;
+    float* dnull_kv[AVI_PRIOR_MAX_DEPTH];
+    float* drel;
+} AviPriorTrainBwd;
+typedef struct AviPriorGainGrads {
+    float* g[AVI_PRIOR_MAX_DEPTH][3];                 /* gradients of norm.g, to_out.1.g, ff 0.g of every layer ([128], written) */
+} AviPriorGainGrads;
+int avi_prior_train_backward(const AviPriorWeights* w, const AviPriorPlanes* pT, const AviPriorTrainBwd* d,
+                             const AviPriorGainGrads* gains, int B, int samples_per_group, void* stream);
 /* Table-driven re-layout of row-major [N][K] 16-bit planes into the fragment-major order of AviPriorPlanes (transpose != 0:
  * the source is the [K][N] plane of the transposed matrix).  jobs_dev: device array; first_block = running sum of
  * ceil(N*K/8/256) over the jobs; N % 16 == 0, K % 32 == 0. */
