@@ -343,10 +343,10 @@ class PriorTrainer:
         import os
         # AVI_TRAIN_FUSED_FWD=0: the forward of the denoiser as the chain of ~55 launches it used to be (A/B switch, tests)
         self.fused_forward = os.environ.get("AVI_TRAIN_FUSED_FWD", "1") == "1"
-        self.fwd_samples_per_group = int(os.environ.get("AVI_TRAIN_FWD_SPG", "2"))   # 32 workgroups at B = 64
+        self.fwd_samples_per_group = int(os.environ.get("AVI_TRAIN_FWD_SPG", "1"))   # one sample per workgroup: 64 CUs at B = 64
         # AVI_TRAIN_FUSED_BWD=0: the dX chain of the denoiser's backward as ~90 launches (needs the fused forward's dumps)
         self.fused_backward = self.fused_forward and os.environ.get("AVI_TRAIN_FUSED_BWD", "1") == "1"
-        self.bwd_samples_per_group = int(os.environ.get("AVI_TRAIN_BWD_SPG", "2"))
+        self.bwd_samples_per_group = int(os.environ.get("AVI_TRAIN_BWD_SPG", "1"))
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
