@@ -467,6 +467,10 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
     for (int i = tid; i < R * DIM; i += NT) d.dtok0[(row0 + i / DIM) * DIM + i % DIM] = s.tok[i / DIM][i % DIM];
 }
 
+// the null-kv gradients are accumulated with atomics: zeroed by this launch first, so that the caller need not clear the
+// gradient buffer (grid depth, 128 threads)
+__global__ __launch_bounds__(128) void prior_zero_null_kv_kernel(AviPriorTrainBwd d) { d.dnull_kv[blockIdx.x][threadIdx.x] = 0.f; }
+
 // gain gradient = sum of the workgroups' partials, in workgroup order: grid (depth * 3), 128 threads
 __global__ __launch_bounds__(128) void prior_gain_grad_kernel(const float* __restrict__ part, int groups, int depth,
                                                                AviPriorGainGrads out) {
@@ -571,6 +575,7 @@ extern "C" int avi_prior_train_backward(const AviPriorWeights* w, const AviPrior
     args.d = *d;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (B + samples_per_group - 1) / samples_per_group;
+    hipLaunchKernelGGL(prior_zero_null_kv_kernel, dim3(w->depth), dim3(128), 0, s, *d);
     hipLaunchKernelGGL(prior_train_bwd_kernel, dim3(groups), dim3(NT), sizeof(SmemB), s, args, B, samples_per_group);
     hipLaunchKernelGGL(prior_gain_grad_kernel, dim3(w->depth * 3), dim3(128), 0, s, d->dgamma_part, groups, w->depth, *gains);
     return avi_launch_status();

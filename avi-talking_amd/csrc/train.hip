@@ -365,9 +365,9 @@ __global__ void prior_tokens_bwd_kernel(const float* __restrict__ dtok, const un
         q += tk[256 + d];
         if (!ki) ni += tk[256 + d];
     }
-    dnull_brain[d] += nb;
-    dnull_image[d] += ni;
-    dlq[d] += q;
+    dnull_brain[d] = nb;      // the only writer of these three gradients: plain stores, no zeroing needed
+    dnull_image[d] = ni;
+    dlq[d] = q;
 }
 
 // ------------------------------------------------------------------ prior attention (3 tokens + null kv), fwd / bwd
@@ -725,13 +725,14 @@ __global__ void rel_bias_kernel(const float* __restrict__ emb, float* __restrict
             const int d = i - j > 0 ? i - j : 0;
             bias[t] = emb[d * heads + h];
         }
-    } else if (t < heads * n) {       // one thread per (bucket d, head): fixed summation order
-        const int d = t / heads, h = t - d * heads;
+    } else if (t < 32 * heads) {      // one thread per (bucket d, head) of the WHOLE (32, heads) table: fixed summation
+        const int d = t / heads, h = t - d * heads;                      // order, plain store (buckets >= n get zero)
         float a = 0.f;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j <= n; ++j)
-                if ((i - j > 0 ? i - j : 0) == d) a += dbias[(h * n + i) * (n + 1) + j];
-        demb[d * heads + h] += a;
+        if (d < n)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= n; ++j)
+                    if ((i - j > 0 ? i - j : 0) == d) a += dbias[(h * n + i) * (n + 1) + j];
+        demb[d * heads + h] = a;
     }
 }
 
@@ -920,7 +921,7 @@ extern "C" int avi_copy_rows(const float* src, long long src_stride, const int* 
 extern "C" int avi_prior_rel_bias(const float* emb, float* bias, const float* dbias, float* demb, int heads, int n,
                                   void* stream) {
     if (!((emb && bias && !dbias && !demb) || (!emb && !bias && dbias && demb))) return AVI_EINVAL;
-    if (heads <= 0 || n <= 0 || heads * n * (n + 1) > 256) return AVI_EINVAL;
+    if (heads <= 0 || n <= 0 || heads * n * (n + 1) > 256 || 32 * heads > 256) return AVI_EINVAL;
     hipLaunchKernelGGL(rel_bias_kernel, dim3(1), dim3(256), 0, S_(stream), emb, bias, dbias, demb, heads, n);
     return avi_launch_status();
 }

@@ -60,6 +60,7 @@ class FlatLayout:
                 self.offset[n], self.shape[n] = off, tuple(shapes[n])
                 off += (math.prod(shapes[n]) + 3) // 4 * 4          # keep every view 16-byte aligned
             if group is dec:
+                off = (off + 7) // 8 * 8                  # the second region starts on a 32-byte boundary (16-byte planes)
                 self.n_decay = off                        # [0, n_decay): weight decay; [n_decay, numel): none
         self.numel = off
         self.names = dec + nod
@@ -588,7 +589,12 @@ class PriorTrainer:
         x = voxel.to(dev, torch.float32).contiguous()
         target = clip_target.reshape(B, DIM).to(dev, torch.float32).contiguous()
         dm = dropout_masks or [None] * (self.n_blocks + 1)
-        L.check(so.avi_zero(S.G.data_ptr(), S.numel, st()), "zero")
+        if not self.fused_backward:
+            # the launch-chain backward adds the null-kv gradients into the buffer with atomics; in the fused path every
+            # gradient element is STORED by exactly one launch (GEMMs, column sums, LayerNorm / gain reductions, token and
+            # relative-bias backward; the null-kv accumulators are cleared by avi_prior_train_backward itself), so the
+            # 311 MB clear is skipped (tests/test_gpu_training.py runs two steps and compares)
+            L.check(so.avi_zero(S.G.data_ptr(), S.numel, st()), "zero")
 
         # ---- BrainNetwork forward (models/diffusion_prior.py:95-117, train mode)
         h0p = self.lin0.fwd(x)

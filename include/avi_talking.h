@@ -352,8 +352,8 @@ int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorPlanes* p, c
  * gain gradients): from `dtok_top`, the gradient at the output of the last layer, to `dtok0`, the gradient of the token
  * rows.  `pT` holds the fragment-major planes of the TRANSPOSED matrices (avi_pack_fragment_planes, transpose = 1).  The
  * output gradient of every matrix is stored for the weight-gradient GEMMs (dy_*: [depth][3B][C], C = 128, 1024, 128, 640 for
- * linear2, linear1, to_out, to_q|to_kv); null_kv and relative-bias gradients are ADDED (atomics) to dnull_kv[l] ([2][64]) and
- * drel ([8][3][4]); dgamma_part: scratch >= ceil(B / samples_per_group) * depth * 3 * 128 floats. */
+ * linear2, linear1, to_out, to_q|to_kv); dnull_kv[l] ([2][64]) is zeroed and then accumulated with atomics, the
+ * relative-bias gradient is ADDED (atomics) to drel ([8][3][4], cleared by the caller); dgamma_part: scratch >= ceil(B / samples_per_group) * depth * 3 * 128 floats. */
 typedef struct AviPriorTrainBwd {
     const float* dtok_top;
     const float *tok_in, *qkv, *o1, *tokm, *hff;      /* forward intermediates (AviPriorTrainDump) */
@@ -386,8 +386,8 @@ int avi_zero(float* p, long long n, void* stream);
 int avi_copy_rows(const float* src, long long src_stride, const int* row_index, float* dst, long long dst_stride,
                   int rows, int C, void* stream);
 /* T5 relative-position bias of the n-token denoiser (dalle2 RelPosBias(n, n+1), models/diffusion_prior.py:159):
- * forward (emb [32][heads] -> bias [heads][n][n+1], dbias = demb = NULL) or backward (demb += scatter of dbias,
- * emb = bias = NULL); distances below 16 are their own bucket, so n <= 16 */
+ * forward (emb [32][heads] -> bias [heads][n][n+1], dbias = demb = NULL) or backward (demb [32][heads] = scatter of dbias,
+ * every entry written, emb = bias = NULL); distances below 16 are their own bucket, so n <= 16 */
 int avi_prior_rel_bias(const float* emb, float* bias, const float* dbias, float* demb, int heads, int n, void* stream);
 /* [R][C] -> [C][R] */
 int avi_transpose(const float* in, int R, int C, float* out, void* stream);

@@ -202,3 +202,29 @@ def test_fused_forward_and_backward_equal_the_launch_chain(gpu, monkeypatch):
                   "net.causal_transformer.layers.2.0.to_out.1.g"):
             a_, b_ = tr0.store.view(n, g1), tr0.store.view(n, g0)
             assert (a_ - b_).abs().max().item() < 1e-3 * b_.abs().max().item() + 1e-7, n
+
+
+def test_gradient_buffer_needs_no_clearing(gpu):
+    """The fused path skips the 311 MB clear of the gradient buffer: every element is stored by exactly one launch.  Poison
+    the buffer, run the same step twice: both runs must give the gradients of a run on a zeroed buffer (atomics on the
+    null-kv entries aside, which differ in summation order only)."""
+    from avi_talking_amd.host.training import PriorTrainer
+    from avi_talking_amd.weights import make_prior_weights
+    tr = PriorTrainer(make_prior_weights(3), device=gpu)
+    assert tr.fused_backward
+    g = torch.Generator().manual_seed(321)
+    B = 64
+    voxel, target = torch.randn(B, 768, generator=g).to(gpu), (torch.randn(B, 1, 128, generator=g) * 0.3).to(gpu)
+    rand = tr.draw(B, generator=torch.Generator(device=gpu).manual_seed(4))
+    run = lambda: tr.forward_backward(voxel, target, rand["times"], rand["noise"], 0.005, rand["brain_keep"],
+                                      rand["image_keep"], rand["dropout_masks"]) and tr.allreduce_grads()
+    tr.store.G.zero_()
+    run()
+    ref = tr.store.G.clone()
+    for poison in (7.0, -3.0e4):
+        tr.store.G.fill_(poison)
+        run()
+        diff = (tr.store.G - ref).abs()
+        worst = int(diff.argmax())
+        name = max((n for n in tr.store.names if tr.store.offset[n] <= worst), key=lambda n: tr.store.offset[n])
+        assert diff.max().item() <= 1e-5 * ref.abs().max().item(), (name, diff.max().item())
