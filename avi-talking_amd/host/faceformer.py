@@ -194,7 +194,9 @@ class Faceformer:
         for b0 in range(0, B, rows_per_call):
             nb = min(rows_per_call, B - b0)
             key = (nb, T, chunk)
-            g = self._graphs.get(key)
+            g = self._graphs.pop(key, None)
+            if g is not None:
+                self._graphs[key] = g                # most recently used last
             if g is None:
                 n = C.c_longlong()
                 L.check(so.avi_faceformer_steps_work_floats(self.D, nb, C.byref(n)), "work size")
@@ -218,6 +220,8 @@ class Faceformer:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     chain()
+                if len(self._graphs) >= 4:           # static buffers per shape: keep the four most recent shapes
+                    self._graphs.pop(next(iter(self._graphs)))
                 g = self._graphs[key] = (graph, st)
             graph, st = g
             st["cross"].copy_(cross[b0:b0 + nb])
