@@ -149,3 +149,38 @@ def test_ragged_and_empty_utterances(gpu):
         assert (outs[i]["predicted_jaw"] - one["predicted_jaw"][0]).abs().max().item() < 1e-5
     with pytest.raises(ValueError):
         pipe.run_many(pcms, voxels[:2], noises)
+
+
+def test_config0_single_4s_clip_and_fixture_wav(gpu):
+    """BASELINE.json configs[0]: one 4 s clip (64 000 samples -> 100 frames) through the whole sampling path with the
+    reference's 100-step DDPM loop, and the reference's own fixture WAV (experiments/wav_dir/0001, channel 0, 79 872
+    samples -> 124 frames, framed by host/audio_io.process_audio): HIP against the CPU oracle, 1e-3 max-abs on the
+    coefficients (un-normalised FLAME expression / jaw)."""
+    import os
+    import numpy as np
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.audio_io import process_audio
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    from oracle import emote as OE, prior as OP, wav2vec2 as OW
+    wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
+    pipe = SamplingPipeline(wa, wh, wp, device=gpu)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 64000, generator=g)
+    X = torch.fft.rfft(x)
+    X[:, int(4000 / 8000 * (X.shape[1] - 1)):] = 0                       # SURVEY 8d: band-limited noise, int16 RMS 3000
+    x = torch.fft.irfft(X, n=64000)
+    clip = (x / x.pow(2).mean().sqrt() * 3000.0).clamp(-32768, 32767).to(torch.int16)
+    fixture = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixture_wav_ch0.npz"))["pcm"]
+    fx = torch.from_numpy(process_audio(fixture, 16000, 25)["raw_audio"].reshape(1, -1).copy())
+    for name, pcm in (("config[0] 4 s clip", clip), ("fixture WAV", fx)):
+        T = pcm.shape[1] // 640
+        voxel = torch.randn(1, 768, generator=g)
+        noise = torch.randn(101, 1, 1, 128, generator=g)
+        out = pipe.run(pcm.to(gpu), voxel.to(gpu), noise.to(gpu))
+        feat = OW.forward(wa, OW.normalize_audio(pcm, joint=False), frame_num=T)
+        te, _ = OP.brain_network(wp, voxel)
+        ref = OE.forward(wh, feat, OP.p_sample_loop(wp, te.view(1, 1, 128), noise))
+        e = max((out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
+                (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
+        print(f"{name}: T = {T}, max-abs coefficient err {e:.2e}")
+        assert out["predicted_exp"].shape == (1, T, 50) and e < 1e-3
