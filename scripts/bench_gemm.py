@@ -22,6 +22,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for name, batch, M, N, K, lda in shapes:
     if only and only not in name:
         continue
+    if batch == 1 and os.environ.get("GEMM_M"):     # fill experiment: rows of the encoder projections
+        M = int(os.environ["GEMM_M"])
     rows = (M - 1) * lda + K
     A = torch.randn(batch, rows, device=dev)
     W = torch.randn(N, K, device=dev) * K ** -0.5

@@ -38,11 +38,13 @@ def test_config1_batch_permutation_and_subbatch(gpu):
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).to(gpu)
     outp = pipe.run(pcm[perm].contiguous(), voxel[perm].contiguous(), noise[:, perm].contiguous())
     assert torch.equal(outp["predicted_exp"], exp[perm]) and torch.equal(outp["predicted_jaw"], jaw[perm])
-    # a sub-batch (different tile fill, different number of sampler workgroups) reproduces its rows
+    # a sub-batch (different tile fill, different number of sampler workgroups) reproduces its rows.  Not bit for bit:
+    # the small conv layers of a 3-clip batch run on the 128-row tile kernels (other summation order; their epilogue
+    # evaluates GELU by the rational erf, the 256 x 256 kernel by its LDS table - both within 5e-7 of the exact GELU)
     sub = [3, 17, 30]
     outs = pipe.run(pcm[sub].contiguous(), voxel[sub].contiguous(), noise[:, sub].contiguous())
-    assert (outs["predicted_exp"] - exp[sub]).abs().max().item() < 1e-5
-    assert (outs["predicted_jaw"] - jaw[sub]).abs().max().item() < 1e-5
+    assert (outs["predicted_exp"] - exp[sub]).abs().max().item() < 3e-5
+    assert (outs["predicted_jaw"] - jaw[sub]).abs().max().item() < 3e-5
     # fully serial reference: everything on the current stream
     side, pipe.side = pipe.side, torch.cuda.current_stream(gpu)
     try:
