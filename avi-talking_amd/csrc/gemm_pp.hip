@@ -233,61 +233,80 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     // has retired before the barrier that ends phase q+1 (WAR: restage >= 2 phases after the last read), and every
     // wave's vmcnt wait for what phase q reads sits in phase q-1 (RAW).
     bf16x8 xh[4], xl[4], w0h[2], w0l[2], w1h[2], w1l[2];
-    auto mem1 = [&](int Tu, int u) __attribute__((always_inline)) {
-        mem_top();
-        issue(KW1, Tu + 1, u ^ 1);
+    // Where the LDS-DMA issue and the counted wait sit.
+    //  * A piece's issue blocks the wave until the CU's vector-memory path takes it (16 pieces per phase per CU at ~37
+    //    cycles each: with the MFMAs switched off a phase takes 600 cycles, with the loads switched off 768), and a wave
+    //    issues in order: with  wait ; issue ; reads ; MFMAs  group A's matrix section started ~600 cycles into the
+    //    phase although the pipe is free after group B's 384, and a phase cost 600 + 384 (measured 1008).  So: fragment
+    //    reads first in every memory section (their LDS latency runs under whatever follows), and group A issues its
+    //    pieces AFTER its matrix section, when the path has drained group B's: its MFMAs follow B's directly (968).
+    //  * Group B reads the fragments of phase q+1 at the END of interval q, so every wave's wait for that data has to
+    //    sit before barrier q-1.  Group B's own wait (top of its memory section of interval q-1, 3 half tiles in flight:
+    //    everything issued <= q-4 has landed, phase q+1 reads what was issued <= q-4) does; group A's used to sit at
+    //    the TOP of interval q - ordered before B's read only by B's 24 MFMAs in between.  It now ends group A's
+    //    interval q-1 (after its issue, before the barrier): same count, same moment, the other side of the barrier.
+    auto rd1 = [&](int u) __attribute__((always_inline)) {
         read_w(u, 0, w0h, w0l);
-        __builtin_amdgcn_sched_barrier(0);
         read_x(u, 0, xh, xl);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto mem2 = [&](int Tu, int u) __attribute__((always_inline)) {
-        mem_top();
-        issue(KX1, Tu + 1, u ^ 1);
+    auto rd2 = [&](int u) __attribute__((always_inline)) {
         read_w(u, 1, w1h, w1l);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto mem3 = [&](int Tu, int u) __attribute__((always_inline)) {
-        mem_top();
-        issue(KX0, Tu + 2, u);
+    auto rd3 = [&](int u) __attribute__((always_inline)) {
         read_x(u, 1, xh, xl);
-    };
-    auto mem4 = [&](int Tu, int u) __attribute__((always_inline)) {
-        mem_top();
-        issue(KW0, Tu + 2, u);
+        __builtin_amdgcn_sched_barrier(0);
     };
     if (wr == 0) {
         for (int T = 0; T < nk; T += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {               // K tile T + u in stage u
-                mem1(T + u, u);
+                rd1(u);
                 quadrant(0, 0, xh, xl, w0h, w0l);
+                issue(KW1, T + u + 1, u ^ 1);
+                mem_top();
                 bar();
-                mem2(T + u, u);
+                rd2(u);
                 quadrant(0, 1, xh, xl, w1h, w1l);
+                issue(KX1, T + u + 1, u ^ 1);
+                mem_top();
                 bar();
-                mem3(T + u, u);
+                rd3(u);
                 quadrant(1, 1, xh, xl, w1h, w1l);
+                issue(KX0, T + u + 2, u);
+                mem_top();
                 bar();
-                mem4(T + u, u);
                 quadrant(1, 0, xh, xl, w0h, w0l);
+                issue(KW0, T + u + 2, u);
+                mem_top();
                 bar();
             }
         }
     } else {
-        mem1(0, 0);
+        rd1(0);
+        issue(KW1, 1, 1);
         for (int T = 0; T < nk; T += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 quadrant(0, 0, xh, xl, w0h, w0l);
-                mem2(T + u, u);
+                mem_top();
+                rd2(u);
+                issue(KX1, T + u + 1, u ^ 1);
                 bar();
                 quadrant(0, 1, xh, xl, w1h, w1l);
-                mem3(T + u, u);
+                mem_top();
+                rd3(u);
+                issue(KX0, T + u + 2, u);
                 bar();
                 quadrant(1, 1, xh, xl, w1h, w1l);
-                mem4(T + u, u);
+                mem_top();
+                issue(KW0, T + u + 2, u);
                 bar();
                 quadrant(1, 0, xh, xl, w0h, w0l);
-                mem1(T + u + 1, u ^ 1);                 // first phase of the next K tile (a dummy after the last)
+                mem_top();
+                rd1(u ^ 1);                             // first phase of the next K tile (a dummy after the last)
+                issue(KW1, T + u + 2, u);
                 bar();
             }
         }

@@ -193,27 +193,43 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     bar();
     // ONE barrier per phase: group A (wr = 0) runs memory -> matrix inside a barrier interval, group B matrix (on the
     // fragments it read in the previous interval) -> memory, so the two waves of a SIMD alternate (gemm_pp.hip).
-    auto mem_even = [&](int Tu, int u) __attribute__((always_inline)) {   // K tile Tu in stage u
+    // Fragment reads before the LDS-DMA issue (gemm_pp.hip: the issue blocks the wave on the CU's vector-memory path; the
+    // reads' latency then runs under it instead of after it).  Group A keeps its issue in front of its matrix section
+    // here (X0 of a K tile is issued only three phases before its first read: issued after the MFMAs it would have one
+    // interval to land), and ENDS its interval with the counted wait: group B reads the fragments of phase q+1 at the
+    // end of interval q, so group A's wait for them has to sit before barrier q-1 (it used to open interval q, ordered
+    // before B's read only by B's MFMAs in between).  Counts: after the even phase's issue X1 of the next K tile and
+    // the NT W pieces just issued may fly (NT + 1), after the odd phase's the NT W and 2 X pieces of the tile after
+    // (NT + 2); group B waits at the top of its memory section, one phase ahead, with the counts of the header.
+    auto mem_even = [&](int Tu, int u) __attribute__((always_inline)) {   // group B: K tile Tu in stage u
         wait_vmcnt<NT + 2>();
-        issue_w(Tu + 2, u == 0 ? 2 : u - 1);
         read_w(u);
-        __builtin_amdgcn_sched_barrier(0);
         read_x(u, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(Tu + 2, u == 0 ? 2 : u - 1);
     };
     auto mem_odd = [&](int Tu, int u) __attribute__((always_inline)) {
         wait_vmcnt<NT + 1>();
-        issue_x(Tu + 2, u == 0 ? 2 : u - 1);
         read_x(u, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(Tu + 2, u == 0 ? 2 : u - 1);
     };
     if (wr == 0) {
         for (int T = 0; T < nk; T += 3) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                mem_even(T + u, u);
+                read_w(u);
+                read_x(u, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_w(T + u + 2, u == 0 ? 2 : u - 1);
                 multiply(0);
+                wait_vmcnt<NT + 1>();
                 bar();
-                mem_odd(T + u, u);
+                read_x(u, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_x(T + u + 2, u == 0 ? 2 : u - 1);
                 multiply(1);
+                wait_vmcnt<NT + 2>();
                 bar();
             }
         }
