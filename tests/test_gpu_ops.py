@@ -257,6 +257,28 @@ def test_planes_gemm_tile_shapes(gpu, M, N, K, budget):
     assert (outp.float().cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, (K / 64) ** 0.5) + 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 768, 768), (200, 2304, 768), (512, 512, 1024)])
+def test_pingpong_gemm_cold_operands(gpu, M, N, K):
+    """Regression for the ping-pong kernels' read / wait order: a few workgroups on freshly written (cache-cold)
+    operands are where a fragment read that is ordered behind the other wave group's counted wait only by timing goes
+    wrong (it did: wav2vec2 at B = 2 when group A issued its LDS-DMA pieces later in the phase).  Every wait now sits a
+    barrier ahead of every reader; fresh operands per round, 256 MB written in between to empty L2 / Infinity Cache."""
+    from avi_talking_amd import ops
+    for rnd in range(6):
+        x, w = _rand((M, K), 100 + rnd), _rand((N, K), 200 + rnd, K ** -0.5)
+        ref = F.linear(x.double(), w.double())
+        pw = ops.PackedWeight(w.to(gpu))
+        xp = ops.Planes((M, K), gpu)
+        hi = x.to(torch.bfloat16)
+        xp.hi.copy_(hi.view(torch.int16).to(gpu))
+        xp.lo.copy_((x - hi.float()).to(torch.bfloat16).view(torch.int16).to(gpu))
+        torch.empty(64 << 20, dtype=torch.float32, device=gpu).fill_(float(rnd))      # evict
+        torch.cuda.synchronize()
+        out = ops.linear_planes(xp, pw).cpu().double()
+        err = (out - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), (rnd, err)
+
+
 def test_transpose_jobs_and_table(gpu):
     """avi_transpose_jobs (jobs by value) and avi_transpose_table (device table): fp32 and split-plane outputs, ragged
     shapes (rows / columns not multiples of the 32x32 block), padded plane rows zero."""
