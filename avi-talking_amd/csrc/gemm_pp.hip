@@ -32,6 +32,7 @@
 //   * LDS image and fragment addressing as in gemm_dma.hip: lane-linear LDS-DMA with the bank swizzle applied on the
 //     SOURCE address (chunk c of row R sits at c ^ (R & 7)); fragments by ds_read_b128, conflict-free.
 #include "common.h"
+#include "gelu_table.h"
 
 namespace {
 
@@ -43,7 +44,7 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // X0 X1 W0 W1
 constexpr int EP_STRIDE = 272;                 // epilogue slab: 64 fp32 + 16 B pad per row
 constexpr int EP_SLAB = 64 * EP_STRIDE;        // per wave
 constexpr int WORK_BYTES = 8 * EP_SLAB > 2 * STAGE_BYTES ? 8 * EP_SLAB : 2 * STAGE_BYTES;   // 136 KiB
-constexpr int TAB_BYTES = 2048;                // GELU table (below), behind the stages / slabs for the whole kernel
+constexpr int TAB_BYTES = 2048;                // GELU table (gelu_table.h), behind the stages / slabs for the whole kernel
 constexpr int SMEM_BYTES = WORK_BYTES + TAB_BYTES;
 constexpr int KX0 = 0, KX1 = 1, KW0 = 2, KW1 = 3;
 
@@ -54,26 +55,9 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-// GELU in the epilogue: 128 outputs per lane through the rational erf of common.h are 22 vector instructions each, and
-// with two waves per SIMD that arithmetic (not the 256 KB of stores) bounds the epilogue: 28-37 k cycles of a 232 k
-// tile against 19-21 k without the activation (in-kernel stamps, conv layer 2).  gelu(x) = max(x, 0) + e(|x|) with
-// e(u) = -u Phi(-u) smooth, even and < 7e-9 beyond u = 6: a piecewise cubic of e on 128 segments (scripts/
-// gen_gelu_table.py, 2.4e-7 = rounding level against float64) costs 10 vector instructions + one 16-byte LDS gather.
-// A NaN input does not propagate through max(x, 0): it yields e(6) (inputs are sums of finite products here).
-__device__ __attribute__((aligned(16))) const float gelu_tab[512] = {
-#include "gelu_table.inc"
-};
-
-__device__ __forceinline__ float gelu_lds(float x, const char* tab) {
-    const float t = __builtin_fminf(__builtin_fabsf(x) * (128.f / 6.f), 127.99999f);
-    const int i = (int)t;
-    const float f = __builtin_amdgcn_fractf(t);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(tab + (i << 4));
-    float r = fmaf(c[3], f, c[2]);
-    r = fmaf(r, f, c[1]);
-    r = fmaf(r, f, c[0]);
-    return __builtin_fmaxf(x, 0.f) + r;
-}
+// GELU in the epilogue comes from the LDS table of gelu_table.h: with two waves per SIMD the activation's arithmetic (not
+// the 256 KB of stores) bounded the epilogue: 28-37 k cycles of a 232 k tile with the rational erf, 25-30 k with the
+// table, 19-21 k without an activation (in-kernel stamps, conv layer 2).
 
 // F16 (with NS = 2): the opt-in 2-term fp16 mode AVI_PREC_F16X2 - activation planes are fp16 hi/lo, the weight is ONE fp16
 // plane (the "lo" half of a staged weight row is a second copy nobody multiplies), y = w.xh + w.xl: two MFMAs per
@@ -220,7 +204,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     issue(KX0, 1, 1);
     issue(KW0, 1, 1);
     if (g.act == AVI_ACT_GELU && wave < 2)
-        glds16(reinterpret_cast<const char*>(gelu_tab) + wave * 1024 + lane * 16, smem + WORK_BYTES + wave * 1024);
+        glds16(reinterpret_cast<const char*>(avi_gelu_tab) + wave * 1024 + lane * 16, smem + WORK_BYTES + wave * 1024);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // X0(0), W0(0), W1(0) have landed
     bar();
 
@@ -373,7 +357,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
             }
             if (g.act == AVI_ACT_GELU) {   // one uniform branch per 8 values, straight-line math inside
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_lds(v[j], smem + WORK_BYTES);
+                for (int j = 0; j < 8; ++j) v[j] = avi_gelu_lds(v[j], smem + WORK_BYTES);
             } else if (g.act != AVI_ACT_NONE) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = avi_act(v[j], g.act);
