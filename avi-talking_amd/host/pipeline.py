@@ -45,7 +45,7 @@ class SamplingPipeline:
                                         cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps,
                                         noise=noise)
 
-    def _body(self, pcm, voxel, noise, clip_voxels=None):
+    def _body(self, pcm, voxel, noise, clip_voxels=None, aligner_on_side=None):
         """Everything up to the join of the two branches: -> (audio features (B,T,768), sampled style (B,1,128)).
         ``clip_voxels``: the aligner's output when it was computed ahead (pipelined replay); None = compute it here."""
         B, N = pcm.shape
@@ -56,7 +56,9 @@ class SamplingPipeline:
         #    workgroups of the audio branch and the sampler starts late (+0.4 ms per step, measured);
         #    AVI_ALIGNER_SIDE=1 selects that arrangement for tests/test_gpu_fullsize.py, which pins that overlapping
         #    short matrix-core launches with conv layer 0 no longer corrupts it (build.py: no packed-FP32 instructions).
-        aligner_on_side = os.environ.get("AVI_ALIGNER_SIDE", "0") == "1" and clip_voxels is None
+        if aligner_on_side is None:
+            aligner_on_side = os.environ.get("AVI_ALIGNER_SIDE", "0") == "1"
+        aligner_on_side = aligner_on_side and clip_voxels is None
         if not aligner_on_side and clip_voxels is None:
             clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
         # 2. fork: the sampler (32 workgroups for ~12 ms) on the side stream, the audio encoder on this one
@@ -107,34 +109,41 @@ class SamplingPipeline:
         self._graph.replay()
         return self._out
 
-    # ---- software-pipelined replay: the serial ends of a pass run beside its neighbours
+    # ---- software-pipelined replay: the serial end of a pass runs beside its successor
     def capture_pipelined(self, pcm, voxel, noise, warmup=2):
-        """Three graphs instead of one.  A pass begins with the aligner (0.17 ms of split-K launches that depend on the text
-        feature alone) and ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip almost idle);
-        between them the two long branches (sampler || audio encoder) keep the chip busy.  Captured as `align`, `body` and
-        `head` and replayed on three streams, the aligner of pass k+1 runs during pass k's branches and the head of pass k
-        beside the start of pass k+1's branches: back-to-back passes cost max(sampler, audio) each.  Hand-offs go through
-        private copies (the aligner's output, the body's two results), guarded by events; every pass still does all of
-        its work and the results are bit-identical to `replay()` (tests/test_gpu_fullsize.py)."""
+        """Two graphs instead of one.  A pass ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip
+        almost idle) and begins with the aligner (0.19 ms of split-K launches that depend on the text feature alone).
+        Captured as `body` and `head` and replayed on two streams, the head of pass k runs beside the start of pass k+1;
+        inside `body` the aligner opens the sampler's branch, beside the audio front end (normalisation and conv layer 0,
+        0.5 ms without matrix-core work: its launches get CUs at once, and the sampler that follows it has 1.5 ms of slack
+        against the audio branch).  Back-to-back passes cost max(aligner + sampler, audio branch) each.  The hand-off goes
+        through private copies of the body's two results, guarded by events; every pass still does all of its work and
+        the results are bit-identical to `replay()` (tests/test_gpu_fullsize.py).
+        A separate aligner graph one pass ahead on a stream of its own was the first design: HIP multiplexes streams onto a
+        few in-order hardware queues, the aligner's stream shared the body's, and its launches ran BETWEEN two bodies
+        (0.19 ms per pass on the critical path, scripts/pass_timeline.py --gap)."""
         from .. import lib as L
         self._static = (pcm.clone(), voxel.clone(), noise.clone())
         for _ in range(warmup):
             self.run(*self._static)
         torch.cuda.synchronize(self.device)
         dev = self.device
-        self._s_align, self._s_body, self._s_head = (torch.cuda.Stream(device=dev) for _ in range(3))
-        self._e_align, self._e_cv_taken, self._e_body, self._e_taken = (torch.cuda.Event() for _ in range(4))
-        B = voxel.shape[0]
-        self._g_align = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_align):
-            self._cv_stage, _ = self.prior.voxel2clip(self._static[1], need_projection=False)
-        self._cv = torch.empty_like(self._cv_stage)
+        # HIP multiplexes streams onto a few IN-ORDER hardware queues, and which queue a stream gets is not ours to choose:
+        # with two streams taken one after the other, the head's launches came out on the body's queue in every trace
+        # and ran between two bodies instead of beside the next one (+0.5 ms per pass); with a first, otherwise unused
+        # stream in front of them the body, the head and the body graph's side branch land on three different queues
+        # (empirical, ROCm 7.2 / torch 2.10; scripts/pass_timeline.py --gap shows the queue of every launch in the
+        # hand-over, so a change of this mapping is visible there before it is in the step time).
+        self._s_spare, self._s_body, self._s_head = (torch.cuda.Stream(device=dev) for _ in range(3))
+        with torch.cuda.stream(self._s_spare):
+            torch.empty(1, device=dev).zero_()
+        self._e_body, self._e_taken = (torch.cuda.Event() for _ in range(2))
         self._g_body = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_body):
-            self._feat, self._style = self._body(*self._static, clip_voxels=self._cv)
+            self._feat, self._style = self._body(*self._static, aligner_on_side=True)
         self._h_feat, self._h_style = torch.empty_like(self._feat), torch.empty_like(self._style)
         self._g_head = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_head):       # pools are NOT shared: the three graphs run concurrently
+        with torch.cuda.graph(self._g_head):       # pools are NOT shared: the two graphs run concurrently
             self._pout = self.talking_head.head(self._h_feat, self._h_style)
             self._pout["style_emb"] = self._h_style
 
@@ -148,14 +157,7 @@ class SamplingPipeline:
 
     def replay_pipelined(self):
         """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised)."""
-        with torch.cuda.stream(self._s_align):
-            self._s_align.wait_event(self._e_cv_taken)   # the previous body has taken the previous aligner output
-            self._g_align.replay()
-            self._e_align.record(self._s_align)
         with torch.cuda.stream(self._s_body):
-            self._s_body.wait_event(self._e_align)
-            self._copy(self._cv_stage, self._cv)
-            self._e_cv_taken.record(self._s_body)
             self._s_body.wait_event(self._e_taken)       # the previous head has copied the previous body's results
             self._g_body.replay()
             self._e_body.record(self._s_body)

@@ -145,8 +145,8 @@ def main():
                          "2-term fp16 (6e-4, inside the 1e-3 gate); bf16 = 1 term (fails the gate)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="replay the pass as ONE graph, passes strictly one after the other (default: three graphs on three "
-                         "streams, the serial ends of a pass - aligner, head - run beside its neighbours' long branches)")
+                    help="replay the pass as ONE graph, passes strictly one after the other (default: two graphs on two "
+                         "streams, the head of a pass runs beside the start of the next; the aligner opens the sampler's branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing (roofline object)")
@@ -242,9 +242,9 @@ def main():
                    "audio_normalisation": "joint over the batch" if args.joint_norm else "per clip",
                    "hipgraph": not args.no_graph,
                    "replay": "eager" if args.no_graph else "one graph per pass" if args.no_pipeline else
-                             "three graphs per pass (aligner, body, head) on three streams: the aligner of pass k+1 runs during "
-                             "pass k and the head of pass k beside the start of pass k+1; every pass does all of its work, "
-                             "results bit-identical to the one-graph replay",
+                             "two graphs per pass (body, head) on two streams: the head of pass k runs beside the start of pass "
+                             "k+1, the aligner opens the sampler's branch beside the audio front end; every pass does all of its "
+                             "work, results bit-identical to the one-graph replay",
                    "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
         "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
