@@ -452,9 +452,9 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         each algorithmic FLOP costs three MFMA FLOPs (`mfma_issued_frac`).
       Sampler: achieved = bytes of weight planes every workgroup streams through its CU (planes x DDPM steps x
         workgroups; served by L2 / Infinity Cache, hence above the HBM-side `traffic`) / launch duration.
-    The `roofline` object is the family with the largest time per step (`frac_of_step` = its time / the measured step:
-    the sampler runs BESIDE the audio branch, so the shares of the two branches each approach 1), `others` the rest in
-    that order.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/."""
+    The `roofline` object is the family with the largest time per step ON THE BRANCH THAT BOUNDS THE STEP (`frac_of_step` =
+    its time / the measured step; the sampler runs BESIDE the audio branch and leads only when its launch fills the
+    step), `others` the rest.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/."""
     from avi_talking_amd import ops
     rec, srec = [], []
     orig = ops.gemm_raw
@@ -578,7 +578,15 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
             "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
             "traffic": t["hbm_bytes_per_launch"] if t else None,
             "mfma_busy_pmc": (next((v for k, v in busy.items() if k.startswith("prior_sample")), {}) or {}).get("mfma_busy_frac")})
-    entries.sort(key=lambda e: -e["ms_per_step"])
+    # Order: time per step.  The sampler runs BESIDE the audio branch: it leads only when its launch fills the step (it then
+    # bounds it: >= 95 %); with slack it is listed second, behind the dominant family of the branch that does bound the step.
+    smp = [e for e in entries if e["kernel"].startswith("prior sampler")]
+    entries = sorted((e for e in entries if e not in smp), key=lambda e: -e["ms_per_step"])
+    if smp:
+        bounds = smp[0]["ms_per_step"] >= 0.95 * step_ms
+        smp[0]["role"] = ("bounds the step" if bounds else
+                          f"beside the audio branch with {step_ms - smp[0]['ms_per_step']:.1f} ms of slack (eager, instrumented pass)")
+        entries.insert(0 if bounds else 1, smp[0])
     out = entries[0]
     out["others"] = entries[1:]
     if tsrc:
