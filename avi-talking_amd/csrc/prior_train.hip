@@ -31,13 +31,13 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
     const AviPriorWeights& w = a.w;
     const AviPriorTrainDump& d = a.d;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+    SmemS& s = *reinterpret_cast<SmemS*>(smem_raw);   // inputs of the linears as split planes (prior_mfma.inc)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * S;
     const int Sg = min(S, B - b0), R = 3 * Sg;
     const long long row0 = 3LL * b0;                       // first token row of this group in the [3B][C] arrays
     const long long RT = 3LL * B;                          // rows per layer in the stacked dumps
-    for (int i = tid; i < MR * XS; i += NT) (&s.x[0][0])[i] = 0.f;
+    for (int i = tid; i < MR * XPS; i += NT) (&s.xh[0][0])[i] = (&s.xl[0][0])[i] = 0;
     for (int i = tid; i < MR * DIM; i += NT) (&s.tok[0][0])[i] = 0.f;
     for (int i = tid; i < w.depth * 3 * DIM; i += NT) {
         const int l = i / (3 * DIM), r = i - l * 3 * DIM, k = r / DIM, dd = r - k * DIM;
@@ -78,15 +78,15 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
             ti[lane] = va;
             ti[lane + 64] = vb;
             ln_row(va, vb, s.gain[l][0], lane, false);
-            s.x[r][lane] = va;
-            s.x[r][lane + 64] = vb;
+            put_x<0>(s, r, lane, va);
+            put_x<0>(s, r, lane + 64, vb);
             float* n1 = d.n1 + ((long long)l * RT + row0 + r) * DIM;
             n1[lane] = va;
             n1[lane + 64] = vb;
         }
         __syncthreads();
         // ---- q | k | v: raw outputs to global (the backward pass applies the rotary itself), rotated ones to LDS
-        Lin<DIM, NQKV>::template run<true>(P.qkv_hi, P.qkv_lo, ring, s, d.qkv + ((long long)l * RT + row0) * NQKV, R);
+        Lin<DIM, NQKV>::template run<true, SmemS, true>(P.qkv_hi, P.qkv_lo, ring, s, d.qkv + ((long long)l * RT + row0) * NQKV, R);
         __syncthreads();
         Lin<INNER, DIM>::prefetch(P.out_hi, P.out_lo, ring);
         {   // ---- attention (prior_mfma.inc phase C): wave = head, lane = dim
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
                     const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
                     const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx), e2 = __expf(s2 - mx), e3 = __expf(s3 - mx);
                     const float o = (e0 * nv + e1 * vd[0] + e2 * vd[1] + e3 * vd[2]) / (e0 + e1 + e2 + e3);
-                    s.x[3 * sm + i][h * DH + lane] = o;
+                    put_x<0>(s, 3 * sm + i, h * DH + lane, o);
                     d.ao[((long long)l * RT + row0 + 3 * sm + i) * INNER + h * DH + lane] = o;
                 }
             }
         }
         __syncthreads();
         // ---- to_out.0
-        Lin<INNER, DIM>::run(P.out_hi, P.out_lo, ring, s, d.o1 + ((long long)l * RT + row0) * DIM, R);
+        Lin<INNER, DIM>::template run<false, SmemS, true>(P.out_hi, P.out_lo, ring, s, d.o1 + ((long long)l * RT + row0) * DIM, R);
         __syncthreads();
         Lin<DIM, 2 * FFI>::prefetch(P.w1_hi, P.w1_lo, ring);
         // ---- to_out.1 LayerNorm, residual, FF pre-LN
@@ -136,27 +136,27 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
             tm[lane] = va;
             tm[lane + 64] = vb;
             ln_row(va, vb, s.gain[l][2], lane, false);
-            s.x[r][lane] = va;
-            s.x[r][lane + 64] = vb;
+            put_x<0>(s, r, lane, va);
+            put_x<0>(s, r, lane + 64, vb);
             float* n2 = d.n2 + ((long long)l * RT + row0 + r) * DIM;
             n2[lane] = va;
             n2[lane + 64] = vb;
         }
         __syncthreads();
         // ---- FF in (value | gate)
-        Lin<DIM, 2 * FFI>::run(P.w1_hi, P.w1_lo, ring, s, d.hff + ((long long)l * RT + row0) * 2 * FFI, R);
+        Lin<DIM, 2 * FFI>::template run<false, SmemS, true>(P.w1_hi, P.w1_lo, ring, s, d.hff + ((long long)l * RT + row0) * 2 * FFI, R);
         __syncthreads();
         Lin<FFI, DIM>::prefetch(P.w2_hi, P.w2_lo, ring);
         // ---- SwiGLU
         for (int o = tid; o < R * FFI; o += NT) {
             const int m = o / FFI, c = o - m * FFI;
             const float v = s.y[m][c] * silu(s.y[m][FFI + c]);
-            s.x[m][c] = v;
+            put_x<0>(s, m, c, v);
             d.sw[((long long)l * RT + row0 + m) * FFI + c] = v;
         }
         __syncthreads();
         // ---- FF out
-        Lin<FFI, DIM>::run(P.w2_hi, P.w2_lo, ring, s);
+        Lin<FFI, DIM>::template run<false, SmemS, true>(P.w2_hi, P.w2_lo, ring, s);
         __syncthreads();
         pending = true;
     }
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
         to[lane] = va;
         to[lane + 64] = vb;
         ln_row(va, vb, s.fin_g, lane, true);
-        s.x[r][lane] = va;
-        s.x[r][lane + 64] = vb;
+        put_x<0>(s, r, lane, va);
+        put_x<0>(s, r, lane + 64, vb);
         float* fn = d.fin + (row0 + r) * DIM;
         fn[lane] = va;
         fn[lane + 64] = vb;
     }
     __syncthreads();
-    Lin<DIM, DIM>::run(a.p.proj_hi, a.p.proj_lo, ring, s, d.po + row0 * DIM, R);
+    Lin<DIM, DIM>::template run<false, SmemS, true>(a.p.proj_hi, a.p.proj_lo, ring, s, d.po + row0 * DIM, R);
 }
 
 // ============================================================================================== fused backward
@@ -183,14 +183,14 @@ __global__ __launch_bounds__(NT, 2) void prior_train_fwd_kernel(const TrainArgs 
 // partial LayerNorm-gain gradients (reduced by one small launch: deterministic) and adding the null-kv / relative-bias
 // gradients with atomics as the stand-alone attention backward does.  Linears run on the TRANSPOSED fragment-major
 // planes (dX = dY . W = Lin over W^T).
-constexpr int XSB = 1028, YSB = 516;
+constexpr int XPB = 1032, YSB = 516;   // XPB: 16-bit plane row stride (K up to 1024): 2064 B = 129 x 16 B, conflict-free fragment reads
 struct AttnB {
     float qn[8][3][64], kn[4][64], vv[4][64], qinv[8][3], kinv[4], p[8][3][4], ds[8][3][4], dkn[4][64];
 };
 struct SmemB {
     float tok[MR][DIM];     // gradient on the residual stream
     float tmid[MR][DIM];    // gradient at the middle of the layer (after attention, before the feed-forward)
-    float x[MR][XSB];
+    uint16_t xh[MR][XPB], xl[MR][XPB];   // input of the next linear, split once by its producer (prior_mfma.inc SmemS)
     float y[MR][YSB];
     float gain[AVI_PRIOR_MAX_DEPTH][3][DIM];
     float relb[96];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
     const int b0 = blockIdx.x * S;
     const int Sg = min(S, B - b0), R = 3 * Sg;
     const long long row0 = 3LL * b0, RT = 3LL * B;
-    for (int i = tid; i < MR * XSB; i += NT) (&s.x[0][0])[i] = 0.f;
+    for (int i = tid; i < MR * XPB; i += NT) (&s.xh[0][0])[i] = (&s.xl[0][0])[i] = 0;
     for (int i = tid; i < MR * DIM; i += NT) {
         (&s.tok[0][0])[i] = 0.f;
         (&s.tmid[0][0])[i] = 0.f;
@@ -371,11 +371,11 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
         for (int i = tid; i < R * DIM; i += NT) {
             const int r = i / DIM, c = i - r * DIM;
             const float v = s.tok[r][c];
-            s.x[r][c] = v;
+            put_x<0>(s, r, c, v);
             d.dy_w2[((long long)l * RT + row0 + r) * DIM + c] = v;
         }
         __syncthreads();
-        Lin<DIM, FFI>::run(P.w2_hi, P.w2_lo, ring, s);                       // dsw [R][512]
+        Lin<DIM, FFI>::template run<false, SmemB, true>(P.w2_hi, P.w2_lo, ring, s);                       // dsw [R][512]
         __syncthreads();
         Lin<2 * FFI, DIM>::prefetch(P.w1_hi, P.w1_lo, ring);
         // ---- SwiGLU backward: hff = (value | gate) from the forward dump
@@ -385,14 +385,14 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
             const float av = hr[c], g = hr[FFI + c], dy = s.y[m][c];
             const float sg = 1.f / (1.f + __expf(-g));
             const float da = dy * g * sg, dgt = dy * av * sg * (1.f + g * (1.f - sg));
-            s.x[m][c] = da;
-            s.x[m][FFI + c] = dgt;
+            put_x<0>(s, m, c, da);
+            put_x<0>(s, m, FFI + c, dgt);
             float* o1 = d.dy_w1 + ((long long)l * RT + row0 + m) * 2 * FFI;
             o1[c] = da;
             o1[FFI + c] = dgt;
         }
         __syncthreads();
-        Lin<2 * FFI, DIM>::run(P.w1_hi, P.w1_lo, ring, s);                   // dn2 [R][128]
+        Lin<2 * FFI, DIM>::template run<false, SmemB, true>(P.w1_hi, P.w1_lo, ring, s);                   // dn2 [R][128]
         __syncthreads();
         Lin<DIM, INNER>::prefetch(P.out_hi, P.out_lo, ring);
         // ---- LayerNorm (ff 0.g) backward on tokm, + residual -> dtokm; LayerNorm (to_out.1.g) backward on o1 -> do1
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
                 s.tmid[r][lane + 64] = db;
                 const float* o1 = d.o1 + ((long long)l * RT + row0 + r) * DIM;
                 ln_bwd_row(o1[lane], o1[lane + 64], da, db, s.gain[l][1], lane, dg + DIM);
-                s.x[r][lane] = da;
-                s.x[r][lane + 64] = db;
+                put_x<0>(s, r, lane, da);
+                put_x<0>(s, r, lane + 64, db);
                 float* dyo = d.dy_out + ((long long)l * RT + row0 + r) * DIM;
                 dyo[lane] = da;
                 dyo[lane + 64] = db;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
             for (int wv = 0; wv < 8; ++wv) v += s.dgw[wv][tid];
             dgp[(l * 3 + (tid < DIM ? 2 : 1)) * DIM + (tid & (DIM - 1))] = v;
         }
-        Lin<DIM, INNER>::run(P.out_hi, P.out_lo, ring, s);                   // dao [R][512]
+        Lin<DIM, INNER>::template run<false, SmemB, true>(P.out_hi, P.out_lo, ring, s);                   // dao [R][512]
         __syncthreads();
         Lin<NQKV, DIM>::prefetch(P.qkv_hi, P.qkv_lo, ring);
         // ---- attention backward, two samples at a time (threads 0..255 / 256..511)
@@ -435,13 +435,13 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
             float* dyq = d.dy_qkv + ((long long)l * RT + row0 + rb) * NQKV;
             auto dout = [&](int i, int c) { return s.y[rb + i][c]; };
             auto dq = [&](int i, int c, float v) {
-                s.x[rb + i][c] = v;
+                put_x<0>(s, rb + i, c, v);
                 dyq[i * NQKV + c] = v;
             };
             attn_bwd_sample(tid & 255, live, qkvb, w.layer[l].null_kv, s.relb, w.rot_cos, w.rot_sin, dout, dq,
                             d.dnull_kv[l], d.drel, s.at[half]);
         }
-        Lin<NQKV, DIM>::run(P.qkv_hi, P.qkv_lo, ring, s);                    // dn1 [R][128]
+        Lin<NQKV, DIM>::template run<false, SmemB, true>(P.qkv_hi, P.qkv_lo, ring, s);                    // dn1 [R][128]
         __syncthreads();
         // ---- LayerNorm (norm.g) backward on the layer's input, + dtokm -> gradient leaving the layer
         {
@@ -541,13 +541,13 @@ extern "C" int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorP
         !d->tok_out || !d->fin || !d->po)
         return AVI_EINVAL;
     static AviLdsGrant lds_grant;
-    lds_grant.ensure(reinterpret_cast<const void*>(prior_train_fwd_kernel), (int)sizeof(Smem));
+    lds_grant.ensure(reinterpret_cast<const void*>(prior_train_fwd_kernel), (int)sizeof(SmemS));
     TrainArgs args;
     args.w = *w;
     args.p = *p;
     args.d = *d;
     const int groups = (B + samples_per_group - 1) / samples_per_group;
-    hipLaunchKernelGGL(prior_train_fwd_kernel, dim3(groups), dim3(NT), sizeof(Smem), static_cast<hipStream_t>(stream), args,
+    hipLaunchKernelGGL(prior_train_fwd_kernel, dim3(groups), dim3(NT), sizeof(SmemS), static_cast<hipStream_t>(stream), args,
                        B, samples_per_group);
     return avi_launch_status();
 }
