@@ -46,8 +46,12 @@ class AviTransposeJob(C.Structure):
                 ("first_block", _i), ("colsum", _vp)]
 
     def blocks(self):
+        """Workgroups of this job in a DEVICE TABLE (avi_transpose_table): plane-only jobs with R % 64 == 0 and
+        C_pad % 64 == 0 run on 64 x 64 tiles, everything else on 32 x 32 (avi_talking.h)."""
         if self.colsum:
             return (self.C + 15) // 16
+        if self.hi and not self.out and self.R % 64 == 0 and self.C_pad % 64 == 0:
+            return (self.C_pad // 64) * (self.R // 64)
         cp = self.C_pad if self.hi else self.C
         return ((cp + 31) // 32) * ((self.R + 31) // 32)
 

@@ -409,7 +409,9 @@ typedef struct AviTransposeJob {
 /* jobs: HOST array of 1..4 jobs, passed to the kernel by value (dY^T and X^T of one backward GEMM pair) */
 int avi_transpose_jobs(const AviTransposeJob* jobs, int njobs, void* stream);
 /* jobs_dev: DEVICE table with first_block filled in, total_blocks = sum of the jobs' blocks (the per-step refresh of
- * every transposed weight plane of the trainer: the table is built once) */
+ * every transposed weight plane of the trainer: the table is built once).  Blocks of a job: ceil(C/16) for a column sum;
+ * (C_pad/64) * (R/64) for a plane-only job (hi/lo set, out NULL) with R % 64 == 0 and C_pad % 64 == 0 (64 x 64 tiles, 16-byte
+ * stores; hi/lo 16-byte aligned); otherwise ceil(Cp/32) * ceil(R/32) with Cp = C_pad for plane jobs, C else. */
 int avi_transpose_table(const AviTransposeJob* jobs_dev, int njobs, int total_blocks, void* stream);
 int avi_colsum(const float* in, int R, int C, float* out, int accumulate, void* stream);     /* out[c] = sum_r */
 int avi_act_fwd(const float* x, long long n, int act, float* y, void* stream);
