@@ -128,15 +128,6 @@ class SamplingPipeline:
             self.run(*self._static)
         torch.cuda.synchronize(self.device)
         dev = self.device
-        # HIP multiplexes streams onto a few IN-ORDER hardware queues, and which queue a stream gets is not ours to choose:
-        # with two streams taken one after the other, the head's launches came out on the body's queue in every trace
-        # and ran between two bodies instead of beside the next one (+0.5 ms per pass); with a first, otherwise unused
-        # stream in front of them the body, the head and the body graph's side branch land on three different queues
-        # (empirical, ROCm 7.2 / torch 2.10; scripts/pass_timeline.py --gap shows the queue of every launch in the
-        # hand-over, so a change of this mapping is visible there before it is in the step time).
-        self._s_spare, self._s_body, self._s_head = (torch.cuda.Stream(device=dev) for _ in range(3))
-        with torch.cuda.stream(self._s_spare):
-            torch.empty(1, device=dev).zero_()
         self._e_body, self._e_taken = (torch.cuda.Event() for _ in range(2))
         self._g_body = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_body):
@@ -152,8 +143,34 @@ class SamplingPipeline:
             L.check(L.load().avi_copy_rows(src.data_ptr(), C_, None, dst.data_ptr(), C_, src.numel() // C_, C_,
                                            L.stream_ptr()), "avi_copy_rows")
         self._copy = copy
+        self._pick_streams()
         torch.cuda.synchronize(dev)
         return self
+
+    def _pick_streams(self, candidates=4, replays=4):
+        """HIP multiplexes streams onto a few IN-ORDER hardware queues, and which queue a stream gets is not ours to choose:
+        with the head's stream on the body's queue the head runs between two bodies instead of beside the next one
+        (+0.5 ms per pass in the kernel trace; with the aligner as a third graph it was the aligner, +0.19 ms).  The
+        graphs do not care which stream replays them, so a few (body, head) stream pairs - taken from torch's pool with
+        0, 1, 2, ... unused streams in between - are TIMED over a few replays and the fastest is kept
+        (scripts/pass_timeline.py --gap shows the queue of every launch in the hand-over)."""
+        import time
+        dev = self.device
+        pool = [torch.cuda.Stream(device=dev) for _ in range(candidates + 1)]
+        best = None
+        for k in range(1, candidates + 1):
+            self._s_body, self._s_head = pool[0], pool[k]
+            self.replay_pipelined()
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            for _ in range(replays):
+                self.replay_pipelined()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t
+            if best is None or dt < best[0]:
+                best = (dt, k)
+        self._streams_kept = pool                      # the unused ones stay alive: their queue slots stay taken
+        self._s_body, self._s_head = pool[0], pool[best[1]]
 
     def replay_pipelined(self):
         """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised)."""
