@@ -331,3 +331,24 @@ def test_transpose_jobs_and_table(gpu):
     L.check(so.avi_transpose_jobs(two, 2, L.stream_ptr()), "avi_transpose_jobs")
     torch.cuda.synchronize()
     assert torch.equal(xt, x.t()) and (cs - x.sum(0)).abs().max().item() < 1e-4
+    # device table with plane-only jobs whose R and C_pad are multiples of 64: the 64 x 64-tile path (16-byte stores), a ragged
+    # column count inside the padded planes, and a 32 x 32 job between them
+    specs = [(128, 190, 256), (192, 640, 640), (70, 45, 64), (64, 64, 64)]
+    tj = (L.AviTransposeJob * len(specs))()
+    keep, total = [], 0
+    for jb, (R, Cc, Cp) in zip(tj, specs):
+        x = torch.randn(R, Cc, generator=g).to(gpu)
+        hi = torch.full((Cp, R), 0x1234, dtype=torch.int16, device=gpu)
+        lo = torch.full((Cp, R), 0x1234, dtype=torch.int16, device=gpu)
+        jb.in_, jb.hi, jb.lo, jb.R, jb.C, jb.C_pad, jb.first_block = x.data_ptr(), hi.data_ptr(), lo.data_ptr(), R, Cc, Cp, total
+        total += jb.blocks()
+        keep.append((x, hi, lo, Cc))
+    assert tj[0].blocks() == 2 * 4 and tj[2].blocks() == 2 * 3
+    table = torch.frombuffer(bytearray(bytes(tj)), dtype=torch.uint8).to(gpu)
+    L.check(so.avi_transpose_table(table.data_ptr(), len(specs), total, L.stream_ptr()), "avi_transpose_table")
+    torch.cuda.synchronize()
+    for x, hi, lo, Cc in keep:
+        v = hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float()
+        assert (v[:Cc] - x.t()).abs().max().item() < 2e-5 * x.abs().max().item()
+        assert torch.equal(hi[:Cc].view(torch.bfloat16), x.t().contiguous().to(torch.bfloat16))
+        assert not v[Cc:].any()
