@@ -48,6 +48,8 @@ class Wav2Vec2Model:
         # (AVI_W2V_TF_PLANES=0: fp32 activations + gemm.hip's 128x128 tiles).
         self.use_planes = os.environ.get("AVI_W2V_PLANES", "1") == "1"
         self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "1") == "1"
+        # positional conv: its own kernel (AVI_W2V_POSCONV=gemm: the overlapping-row GEMM per (clip, group) on gemm.hip)
+        self.posconv_kernel = os.environ.get("AVI_W2V_POSCONV", "kernel") != "gemm"
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -120,6 +122,9 @@ class Wav2Vec2Model:
     def encoder(self, hp):
         B, T, _ = hp.shape
         cg = HIDDEN // POS_G
+        if self.posconv_kernel:      # one launch, the input window resident in LDS (csrc/posconv.hip)
+            h = ops.posconv_gelu_residual(hp, self.pos, self.pos_bias, POS_G, POS_K, 64)
+            return self._encoder_layers(h)
         xg = ops.group_pad_pack(hp, POS_G, POS_K // 2)
         h = torch.empty_like(hp)
         Tp = T + POS_K
@@ -128,6 +133,9 @@ class Wav2Vec2Model:
                      R=hp.data_ptr(), ldr=HIDDEN, act=ops.ACT_GELU, prec=self.prec, batch=B * POS_G, z_inner=POS_G,
                      sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
                      sR=(T * HIDDEN, cg))
+        return self._encoder_layers(h)
+
+    def _encoder_layers(self, h):
         d = HIDDEN // HEADS
         if not self.use_planes_tf:
             h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)

@@ -131,6 +131,7 @@ SIGNATURES = {
     "avi_layernorm": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "avi_layernorm_act": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "avi_group_pad_pack": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "avi_posconv_gelu_residual": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "avi_pad_repeat": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "avi_add_rowbcast": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "avi_embed_tokens": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -228,6 +228,18 @@ def linear_ln_skinny(x, pw, gamma=None, beta=None, eps=1e-5, do_ln=True, act=ACT
     return out
 
 
+def posconv_gelu_residual(x, pw, bias, groups, taps, rows_per_group):
+    """x + gelu(grouped Conv1d(x, k=taps, padding=taps/2)[:-1] + bias) for x (B, T, C): wav2vec2's positional embedding.
+    pw: PackedWeight of [groups * rows_per_group][taps * C/groups] (tap-major), rows beyond C/groups per group zero."""
+    x = _f32c(x, "x")
+    B, T, Cc = x.shape
+    out = torch.empty_like(x)
+    L.check(L.load().avi_posconv_gelu_residual(x.data_ptr(), B, T, Cc, groups, taps, pw.hi.data_ptr(), pw.lo.data_ptr(),
+                                               rows_per_group, bias.data_ptr(), out.data_ptr(), L.stream_ptr()),
+            "avi_posconv_gelu_residual")
+    return out
+
+
 def group_pad_pack(h, G, pad):
     h = _f32c(h, "h")
     B, T, Cc = h.shape

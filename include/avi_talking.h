@@ -142,6 +142,12 @@ int avi_layernorm_act(const float* in, int rows, int C, const float* gamma, cons
 
 /* pos-conv input packing: h [B][T][G*Cg] -> xg [B][G][T+2*pad][Cg], zero padded (pad = 64, Cg = 48). */
 int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, float* xg, void* stream);
+/* wav2vec2's positional conv embedding in one launch (HF Wav2Vec2PositionalConvEmbedding behind models/lib/wav2vec.py:142-148):
+ * out[b][t][:] = x[b][t][:] + gelu(conv1d(x, k = taps, groups, padding = taps/2)[t] + bias), last extra frame dropped.
+ * x, out [B][T][C] fp32 (C = groups * 48, taps = 128: wav2vec2-base); w_hi / w_lo: bf16 hi / lo planes
+ * [groups][rows_per_group >= 48][taps * 48], W[g][n][tap * 48 + ch] = conv.weight[g * 48 + n][ch][tap] (weight norm folded). */
+int avi_posconv_gelu_residual(const float* x, int B, int T, int C, int groups, int taps, const uint16_t* w_hi,
+                              const uint16_t* w_lo, int rows_per_group, const float* bias, float* out, void* stream);
 
 /* time-axis padding / repetition: in [B][T][C] -> out [B][padL + T*rep + padR][C];
  * mode 0 zeros, 1 replicate edge rows (Conv1d padding_mode='replicate', L2lMotionPrior.py:387). */

@@ -279,6 +279,27 @@ def test_pingpong_gemm_cold_operands(gpu, M, N, K):
         assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), (rnd, err)
 
 
+@pytest.mark.parametrize("B,T", [(2, 250), (1, 100), (3, 129), (1, 7)])
+def test_posconv_gelu_residual(gpu, B, T):
+    """wav2vec2's positional conv embedding in one launch (csrc/posconv.hip) against torch's grouped Conv1d:
+    x + gelu(conv1d(x, k=128, groups=16, padding=64)[..., :-1] + bias); frames at the clip's ends see the zero padding."""
+    from avi_talking_amd import ops
+    G, K, Cc = 16, 128, 768
+    cg = Cc // G
+    x = _rand((B, T, Cc), 31)
+    w = _rand((Cc, cg, K), 32, (cg * K) ** -0.5 * 2)
+    bias = _rand((Cc,), 33)
+    ref = x.double() + F.gelu(F.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), padding=K // 2,
+                                       groups=G)[..., :-1]).transpose(1, 2)
+    wg = w.view(G, cg, cg, K).permute(0, 1, 3, 2).reshape(G, cg, K * cg)          # [g][n][tap * 48 + ch]
+    wpad = torch.zeros((G, 64, K * cg))
+    wpad[:, :cg] = wg
+    pw = ops.PackedWeight(wpad.reshape(G * 64, K * cg).to(gpu))
+    out = ops.posconv_gelu_residual(x.to(gpu), pw, bias.to(gpu), G, K, 64).cpu().double()
+    err = (out - ref).abs().max().item()
+    assert err < 5e-5, err
+
+
 def test_transpose_jobs_and_table(gpu):
     """avi_transpose_jobs (jobs by value) and avi_transpose_table (device table): fp32 and split-plane outputs, ragged
     shapes (rows / columns not multiples of the 32x32 block), padded plane rows zero."""
