@@ -8,16 +8,18 @@
 // and the matrix pipe idles ~55 % of the cycles.  Here the two waves of a SIMD ALTERNATE:
 //
 //   * one workgroup of 8 waves (2 along m x 4 along n, 128 x 64 outputs each) per CU, 128 KiB of LDS for the stages;
-//   * a phase = [memory section: counted vmcnt wait, 2 LDS-DMA pieces, 0..12 ds_read_b128] + [matrix section: the MFMAs
-//     of one quadrant of the wave's tile (24 in bf16x3, 16 in bf16)] + ONE s_barrier.  The 4 waves with wr = 0
-//     ("group A") run memory -> matrix inside a barrier interval, the 4 with wr = 1 ("group B") matrix -> memory (their
-//     fragments were read in the previous interval), so on every SIMD one wave multiplies while the other loads;
+//   * a phase = [memory work: 0..12 ds_read_b128 of fragments, 2 LDS-DMA pieces, a counted vmcnt wait] + [matrix section:
+//     the MFMAs of one quadrant of the wave's tile (24 in bf16x3, 16 in bf16)] + ONE s_barrier.  The 4 waves with wr = 0
+//     ("group A") run  reads -> MFMAs -> issue -> wait  inside a barrier interval, the 4 with wr = 1 ("group B")
+//     MFMAs -> wait -> reads -> issue  (their fragments were read in the previous interval), so on every SIMD one wave
+//     multiplies while the other loads (the order inside the sections is derived in front of the K loop below);
 //   * a K tile (32 k in bf16x3: rows of [hi 64 B | lo 64 B]; 64 k in bf16: rows of 128 B) is staged as FOUR half
 //     tiles (X0 X1 W0 W1: the rows the quadrant m-half / n-half of every wave needs), two stages, one half tile per
 //     phase, each issued FIVE or six phases before its first read.  Hazards, in phases (cdna_hip_programming.md
 //     section 5, "Read a staged buffer one phase after the wait that retires it"):
-//       RAW  the wait for a half tile read in phase q sits at the top of the memory section of phase q-1 (group B's
-//            wait and group A's read are then separated by the barrier of phase q-1);
+//       RAW  every wave's wait for a half tile sits a BARRIER ahead of its first reader.  Group B reads the fragments of
+//            phase q+1 at the end of interval q: group B's own wait (in its memory work of interval q-1) and group A's
+//            (it ends group A's interval q-1, in front of the barrier) both precede barrier q-1;
 //       WAR  a slot is restaged >= 2 phases after its last ds_read (group B's read of phase q retires before its
 //            matrix section in interval q+1, i.e. before the barrier group A passes on its way to phase q+2).
 //     Per K tile T (stage s = T & 1):   reads            matrix quadrant   LDS-DMA issue
@@ -25,8 +27,8 @@
 //       P2                               W1(T)            (m0, n1)          X1(T+1) -> stage s^1
 //       P3                               X1(T)            (m1, n1)          X0(T+2) -> stage s
 //       P4                               -                (m1, n0)          W0(T+2) -> stage s
-//     Every memory section starts with `s_waitcnt vmcnt(6)`: the 3 half tiles (6 pieces per wave) issued after the
-//     one the NEXT phase reads may stay in flight - 48-64 KiB per CU is always on its way.
+//     The wait is always `s_waitcnt vmcnt(6)`: the 3 half tiles (6 pieces per wave) issued most recently may stay in
+//     flight - 48-64 KiB per CU is always on its way.
 //   * past the end of K the issue slots load the last K tile again into slots nobody reads any more, which keeps
 //     the vmcnt arithmetic uniform (3 % extra L2 reads at K = 1536).
 //   * LDS image and fragment addressing as in gemm_dma.hip: lane-linear LDS-DMA with the bank swizzle applied on the

@@ -1,8 +1,9 @@
 // 128 x 192 tile variant of the ping-pong GEMM (gemm_pp.hip) for the transformer projections of the audio encoder
 // (M = 8000 rows, N = 768 / 2304 / 3072: 63 x 4 / 12 / 16 tiles = 0.98 / 2.95 / 3.94 rounds of 256 CUs, where the
 // 256 x 256 tile gives 0.38 / 1.13 / 1.5).  Same contract and the same idea - the two waves of a SIMD alternate between
-// a memory section (counted vmcnt wait, LDS-DMA pieces, ds_read_b128 fragments) and a matrix section, one s_barrier
-// per phase, group A memory -> matrix and group B (wr = 1) matrix -> memory inside a barrier interval - with the
+// memory work (ds_read_b128 fragments, LDS-DMA pieces, a counted vmcnt wait) and a matrix section, one s_barrier
+// per phase, group A reads -> issue -> MFMAs -> wait and group B (wr = 1) MFMAs -> wait -> reads -> issue inside a barrier
+// interval - with the
 // schedule re-derived for the smaller tile:
 //
 //   * 8 waves = 2 (m) x 4 (n), 64 x 48 outputs each (4 x 3 accumulator tiles);
@@ -12,9 +13,11 @@
 //       h = 1   reads X1(T)           multiplies m-tiles 2,3 (W fragments stay in registers)      issues X0(T+2), X1(T+2)
 //     WAR  an area is restaged >= 2 phases after its last read (W(T-1), X0(T-1) read in phase 2T-2, X1(T-1) in 2T-1;
 //          restaged in phases 2T and 2T+1);
-//     RAW  the wait for an area read in phase q sits at the top of phase q-1, before that phase's own issues:
-//          odd phases wait `vmcnt(4)` (X0, W of the next K tile have landed; X1 of it and the 3 W pieces of the tile
-//          after may fly), even phases `vmcnt(5)` (X1 of this K tile; 3 W + 2 X pieces may fly).
+//     RAW  every wave's wait for an area sits a barrier ahead of its first reader (group B reads the fragments of phase
+//          q+1 at the end of interval q).  Group B waits at the top of its memory work, before that phase's own issues:
+//          `vmcnt(4)` before an odd phase's (X0, W of the next K tile have landed; X1 of it and the 3 W pieces of the
+//          tile after may fly), `vmcnt(5)` before an even phase's (X1 of this K tile; 3 W + 2 X pieces may fly); group A
+//          ends its interval with the same counts, after its issue (derived in front of the K loop).
 //   * the K loop is unrolled by three K tiles so every LDS offset is an immediate (K tiles must come in threes:
 //     K % 96 == 0 in bf16x3, K % 192 == 0 in bf16); past the end of K the issue slots reload the last K tile.
 //   * epilogue: per-wave LDS transposition (64 rows x 48 columns, row stride 208 B), then 16-B stores along rows.
