@@ -168,6 +168,42 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
     }
 }
 
+// Input rows of the teacher-forced pass (models/faceformer.py:382-384): x[b][t] = vertice_map(coeff[b][t-1]) + pe[t % period],
+// coeff[b][-1] = 0 (the shift-right start token).  One workgroup per TF_ROWS frames; the 53 x D map streams from L2.
+constexpr int TF_ROWS = 8;
+__global__ __launch_bounds__(NT) void faceformer_tf_embed_kernel(const float* __restrict__ coeff,
+                                                                  const float* __restrict__ wm_t,
+                                                                  const float* __restrict__ bm,
+                                                                  const float* __restrict__ pe, int B, int T, int V,
+                                                                  int D, int period, float* __restrict__ out) {
+    __shared__ float c[TF_ROWS][64];
+    const long long row0 = (long long)blockIdx.x * TF_ROWS, rows = (long long)B * T;
+    for (int e = threadIdx.x; e < TF_ROWS * 64; e += NT) {
+        const int r = e >> 6, v = e & 63;
+        const long long row = row0 + r;
+        float x = 0.f;
+        if (row < rows && v < V && row % T != 0) x = coeff[(row - 1) * V + v];
+        c[r][v] = x;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += NT) {
+        float acc[TF_ROWS];
+#pragma unroll
+        for (int r = 0; r < TF_ROWS; ++r) acc[r] = 0.f;
+        for (int v = 0; v < V; ++v) {
+            const float w = wm_t[(long long)v * D + d];
+#pragma unroll
+            for (int r = 0; r < TF_ROWS; ++r) acc[r] = fmaf(c[r][v], w, acc[r]);
+        }
+        const float b = bm[d];
+#pragma unroll
+        for (int r = 0; r < TF_ROWS; ++r) {
+            const long long row = row0 + r;
+            if (row < rows) out[row * D + d] = acc[r] + b + pe[(long long)((row % T) % period) * D + d];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
@@ -195,4 +231,15 @@ extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, cons
 extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,
                                      float* out, void* stream) {
     return avi_faceformer_decode_chunked(w, cross, B, T, T, kv_scratch, out, stream);
+}
+
+extern "C" int avi_faceformer_tf_embed(const AviFaceformerWeights* w, const float* coeff, int B, int T, float* out,
+                                       void* stream) {
+    if (!w || !coeff || !out || B <= 0 || T <= 0) return AVI_EINVAL;
+    if (w->D < 1 || w->V < 1 || w->V > 64 || w->period < 1 || !w->wm || !w->bm || !w->pe) return AVI_EINVAL;
+    const long long rows = (long long)B * T;
+    if ((rows + TF_ROWS - 1) / TF_ROWS > 0x7fffffffLL) return AVI_EINVAL;
+    hipLaunchKernelGGL(faceformer_tf_embed_kernel, dim3((unsigned)((rows + TF_ROWS - 1) / TF_ROWS)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), coeff, w->wm, w->bm, w->pe, B, T, w->V, w->D, w->period, out);
+    return avi_launch_status();
 }

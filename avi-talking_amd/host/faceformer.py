@@ -85,6 +85,7 @@ class Faceformer:
         self.cross_v = ops.PackedWeight(dv(Wc[2 * D:]), dv(bc[2 * D:]))
         self.cross_o = ops.PackedWeight(dv(w[p + "multihead_attn.out_proj.weight"]),
                                         dv(w[p + "multihead_attn.out_proj.bias"]))
+        self._w, self._p, self._tf = w, p, None          # the teacher-forced pass packs its matrices on first use
         self._keep = []
 
         def dev(t):
@@ -229,23 +230,99 @@ class Faceformer:
             out[b0:b0 + nb] = st["out"]
         return out
 
-    @torch.no_grad()
-    def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None, chunk=None):
+    def _audio_memory(self, audio, cond_embeds=None, frame_num=None):
+        """:673-674 (+ :707-708): audio -> wav2vec2 -> audio_feature_map (-> v_merge2hidden) = the decoder's memory."""
         if self.audio_encoder is None:
             raise RuntimeError("Faceformer was built without audio encoder weights")
-        feats = self.audio_encoder(audio.to(self.device), "vocaset").last_hidden_state     # :673
-        hs = ops.linear(feats, self.audio_feature_map, prec=self.prec)                     # :674
-        if cond_embeds is not None:
-            if self.v_merge2hidden is None:
-                raise RuntimeError("cond_embeds given but the state_dict has no v_merge2hidden")
-            eye, emo, head = [t.to(self.device, torch.float32) for t in cond_embeds]
-            B, T, _ = hs.shape
-            cat = torch.zeros((B, T, self.v_merge2hidden.K), dtype=torch.float32, device=self.device)
-            o = 0
-            for part in (eye, emo, hs, head):                                              # :707
-                cat[..., o:o + part.shape[-1]] = part
-                o += part.shape[-1]
-            if o != self.merge_in:
-                raise ValueError("cond_embeds do not match v_merge2hidden's input width")
-            hs = ops.linear(cat, self.v_merge2hidden, prec=self.prec)                      # :708
-        return self.decode(hs, chunk=chunk)
+        feats = self.audio_encoder(audio.to(self.device), "vocaset", frame_num=frame_num).last_hidden_state
+        hs = ops.linear(feats, self.audio_feature_map, prec=self.prec)
+        if cond_embeds is None:
+            return hs
+        if self.v_merge2hidden is None:
+            raise RuntimeError("cond_embeds given but the state_dict has no v_merge2hidden")
+        eye, emo, head = [t.to(self.device, torch.float32) for t in cond_embeds]
+        B, T, _ = hs.shape
+        cat = torch.zeros((B, T, self.v_merge2hidden.K), dtype=torch.float32, device=self.device)
+        o = 0
+        for part in (eye, emo, hs, head):                                              # :707
+            cat[..., o:o + part.shape[-1]] = part
+            o += part.shape[-1]
+        if o != self.merge_in:
+            raise ValueError("cond_embeds do not match v_merge2hidden's input width")
+        return ops.linear(cat, self.v_merge2hidden, prec=self.prec)                    # :708
+
+    @torch.no_grad()
+    def forward_teacher_forced(self, hidden_states, coeff):
+        """The teacher-forced decoder pass (models/faceformer.py:378-391) for memory ``hidden_states`` (B,T,D) and
+        NORMALISED ground-truth coefficients ``coeff`` (B,T,>=V): shift-right -> ``vertice_map`` -> PPE -> one
+        ``TransformerDecoderLayer`` (ALiBi-causal self-attention, diagonal cross-attention, ReLU FFN, post-LN) ->
+        ``vertice_map_r``; returns the normalised prediction (B,T,V) for all frames at once.
+
+        The reference runs it one utterance at a time (its 3-D float mask only fits batch 1, :376); here the batch is
+        one pass: M = B*T rows through avi_gemm, avi_attention with bias mode 2 (the (4,T,T) mask evaluated
+        analytically), and the diagonal memory mask turned into cross_i = out_proj(v_proj(memory_i))."""
+        hs = hidden_states.to(self.device, torch.float32).contiguous()
+        B, T, D = hs.shape
+        if D != self.D:
+            raise ValueError(f"hidden_states has D={D}, decoder has D={self.D}")
+        if T > self.max_seq_len:
+            raise ValueError(f"T={T} exceeds the reference's mask/PPE length {self.max_seq_len}")
+        c = coeff.to(self.device, torch.float32)
+        if c.dim() != 3 or c.shape[0] != B or c.shape[1] != T or c.shape[2] < self.V:
+            raise ValueError(f"coeff must be (B={B}, T={T}, >={self.V}), got {tuple(c.shape)}")
+        c = c[..., :self.V].contiguous()                                 # the models slice [:53] (:414)
+        if self._tf is None:
+            w, p = self._w, self._p
+            dv = lambda t: t.to(self.device).contiguous()
+            pw = lambda wk, bk: ops.PackedWeight(dv(w[wk]), dv(w[bk]))
+            self._tf = dict(
+                qkv=pw(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias"),
+                out=pw(p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias"),
+                l1=pw(p + "linear1.weight", p + "linear1.bias"), l2=pw(p + "linear2.weight", p + "linear2.bias"),
+                vr=pw("vertice_map_r.weight", "vertice_map_r.bias"),
+                norms=[(dv(w[p + f"norm{i}.weight"]), dv(w[p + f"norm{i}.bias"])) for i in (1, 2, 3)],
+                slopes=torch.tensor(alibi_slopes(NHEAD), dtype=torch.float32, device=self.device))
+        tf, P = self._tf, self.prec
+        x = torch.empty((B, T, D), dtype=torch.float32, device=self.device)
+        L.check(L.load().avi_faceformer_tf_embed(C.byref(self.cw), c.data_ptr(), B, T, x.data_ptr(), L.stream_ptr()),
+                "avi_faceformer_tf_embed")                                                       # :382-384
+        dh = D // NHEAD
+        qkv = ops.linear(x, tf["qkv"], prec=P)
+        att = ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], NHEAD, dh, 3 * D, 3 * D, T, T, B,
+                            dh ** -0.5, bias_mode=2, slopes=tf["slopes"], period=self.period)   # tgt_mask (:385)
+        x = ops.layernorm(ops.linear(att, tf["out"], residual=x, prec=P), *tf["norms"][0])
+        cv = ops.linear(hs, self.cross_v, prec=P)                                                # memory_mask (:387)
+        x = ops.layernorm(ops.linear(cv, self.cross_o, residual=x, prec=P), *tf["norms"][1])
+        f = ops.linear(x, tf["l1"], act=ops.ACT_RELU, prec=P)
+        x = ops.layernorm(ops.linear(f, tf["l2"], residual=x, prec=P), *tf["norms"][2])
+        return ops.linear(x, tf["vr"], prec=P)                                                   # :391
+
+    @torch.no_grad()
+    def forward(self, audio, coeff, criterion=None, teacher_forcing=True, cond_embeds=None, lip_coeff_weight=1.0):
+        """The coefficient term of ``Faceformer.forward`` (models/faceformer.py:316-415): memory from the audio
+        (``frame_num`` = the coefficient length, :330), the teacher-forced pass (or the AR loop, :392-409), then
+        ``mean(criterion(pred[..., :53], coeff[..., :53]) * lip_coeff_weight)`` (:413-415; ``criterion`` defaults to the
+        element-wise squared error the reference passes, ``nn.MSELoss(reduction='none')``).  The render / landmark /
+        emotion losses that follow in the reference need external renderers and are out of scope.
+        Returns (loss, prediction)."""
+        T = coeff.shape[1]
+        hs = self._audio_memory(audio, cond_embeds, frame_num=T)
+        c = coeff.to(self.device, torch.float32)[..., :self.V].contiguous()
+        if teacher_forcing:
+            pred = self.forward_teacher_forced(hs, c)
+        else:
+            if self.cw.coeff_mean:
+                raise RuntimeError("the AR branch of forward() compares NORMALISED coefficients: build the decoder "
+                                   "without coeff_mean/std")
+            pred = self.decode(hs)
+        if criterion is not None:
+            return torch.mean(criterion(pred, c) * lip_coeff_weight), pred
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dpred = torch.empty_like(pred)                 # weight * dloss/dpred: what a trainer would start backward from
+        L.check(L.load().avi_mse_loss(pred.data_ptr(), c.data_ptr(), pred.numel(), float(lip_coeff_weight),
+                                      loss.data_ptr(), dpred.data_ptr(), L.stream_ptr()), "avi_mse_loss")
+        return loss[0] * lip_coeff_weight, pred
+
+    @torch.no_grad()
+    def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None, chunk=None):
+        return self.decode(self._audio_memory(audio, cond_embeds), chunk=chunk)

@@ -304,6 +304,12 @@ int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int
 int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
                                   float* kv_scratch, float* out, void* stream);
 
+/* Input rows of the TEACHER-FORCED decoder pass (models/faceformer.py:382-384): out[b][t] = vertice_map(coeff[b][t-1]) +
+ * pe[t mod period] with coeff[b][-1] = 0 (`torch.cat([zeros_like(coeff[:, -1:]), coeff[:, :-1]], 1)`), coeff [B][T][V]
+ * normalised coefficients, out [B][T][D]; fp32 on the vector pipe (K = 53).  The rest of the pass (:385-391) is
+ * avi_gemm / avi_attention (bias mode 2) / avi_layernorm_act, see avi-talking_amd/host/faceformer.py. */
+int avi_faceformer_tf_embed(const AviFaceformerWeights* w, const float* coeff, int B, int T, float* out, void* stream);
+
 /* The same decode for WIDE decoders (D >= 256; config/vocaset/demo.yaml uses feature_dim 1024) as a chain of small
  * launches per frame, every one spread over the whole chip, instead of one workgroup per utterance streaming all
  * 8 D^2 weights through one CU per frame: self-attention as split-key partials over the KV cache, the four Linear

@@ -15,6 +15,8 @@ What is pinned:
                      ``__new__`` + hand-attached submodules (``__init__`` needs FLAME assets, the network and
                      files that do not exist in the repo); the FAN image encoder (out of scope) is a stub
                      returning zero embeddings.
+  * faceformer_tf.npz the teacher-forced decoder pass (models/faceformer.py:378-391) on the reference's own submodules,
+                     D = 64 and 1024, T = 49 and 250.
   * flame.npz        inferno ``utils/lbs.py`` ``lbs`` (imported as is: pure torch) on the synthetic FLAME basis of
                      avi_talking_amd.weights.make_flame_basis, with the pose assembly of ``FLAME.forward``
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
@@ -210,6 +212,66 @@ def gen_faceformer(ff):
         np.savez_compressed(os.path.join(HERE, f"faceformer_D{D}.npz"), n_samples=np.int64(n_samples),
                             hidden_states=hidden.numpy(), predict=out.numpy())
         print("faceformer", D, tuple(out.shape))
+
+
+def _reference_faceformer(ff, D, with_audio=True):
+    """``models/faceformer.py`` ``Faceformer`` built with ``__new__`` + hand-attached submodules of the ctor's own
+    types (:138-158); returns the module and the state_dict it was loaded from."""
+    from transformers import Wav2Vec2Config
+    ref_w2v = sys.modules["models.lib.wav2vec"]
+    w = W.make_faceformer_weights(2, feature_dim=D)
+    m = ff.Faceformer.__new__(ff.Faceformer)
+    torch.nn.Module.__init__(m)
+    m.args = types.SimpleNamespace(load_mld=0, period=30, feature_dim=D, vertice_dim=53)
+    m.dataset = "vocaset"
+    m.device = "cpu"
+    if with_audio:
+        m.audio_encoder = ref_w2v.Wav2Vec2Model(Wav2Vec2Config(attn_implementation="eager"))
+        m.audio_encoder.load_state_dict(W.make_wav2vec2_weights(0), strict=True)
+    m.audio_feature_map = torch.nn.Linear(768, D)
+    m.vertice_map = torch.nn.Linear(53, D)
+    m.PPE = ff.PeriodicPositionalEncoding(D, period=30)
+    m.biased_mask = ff.init_biased_mask(n_head=4, max_seq_len=600, period=30)
+    layer = torch.nn.TransformerDecoderLayer(d_model=D, nhead=4, dim_feedforward=2 * D, batch_first=True)
+    m.transformer_decoder = torch.nn.TransformerDecoder(layer, num_layers=1)
+    m.vertice_map_r = torch.nn.Linear(D, 53)
+    m.obj_embedding = torch.nn.Parameter(torch.zeros(1, D))
+    return m, w
+
+
+def gen_faceformer_teacher_forced(ff):
+    """The teacher-forced decoder pass of ``Faceformer.forward_switch_frame`` (models/faceformer.py:378-391): the
+    statements of those lines executed on the reference's own submodules (``vertice_map``, ``PPE``, ``biased_mask``,
+    module-level ``enc_dec_mask``, ``transformer_decoder``, ``vertice_map_r``) - the method itself cannot run (FAN image
+    encoder, ``coeff2style``, FLAME criterion).  ``hidden_states`` stands for ``hidden_states_mix[j:j+1]`` (:376).
+    Inputs are stored rounded to fp16 (exactly representable), outputs in full."""
+    out = {}
+    for D in (64, 1024):
+        m, w = _reference_faceformer(ff, D, with_audio=False)
+        missing = m.load_state_dict(w, strict=False)
+        assert not [k for k in missing.missing_keys if not k.startswith("PPE")], missing
+        assert not missing.unexpected_keys, missing
+        m.eval()
+        for T in (49, 250):
+            g = torch.Generator().manual_seed(100 + T)
+            hidden_states = torch.randn(1, T, D, generator=g).half().float()
+            coeff = (torch.randn(1, T, 53, generator=g) * 0.7).half().float()
+            with torch.no_grad():
+                # --- models/faceformer.py:382-391, statement by statement -------------------------------------
+                vertice_input = torch.cat([torch.zeros_like(coeff[:, -1:]), coeff[:, :-1]], 1)
+                vertice_input = m.vertice_map(vertice_input)
+                vertice_input = m.PPE(vertice_input)
+                tgt_mask = m.biased_mask[:, :vertice_input.shape[1], :vertice_input.shape[1]].clone().detach().to(
+                    device=m.device)
+                memory_mask = ff.enc_dec_mask(m.device, m.dataset, vertice_input.shape[1], hidden_states.shape[1])
+                vertice_out = m.transformer_decoder(vertice_input, hidden_states, tgt_mask=tgt_mask,
+                                                    memory_mask=memory_mask)
+                vertice_out = m.vertice_map_r(vertice_out)
+            out[f"D{D}_T{T}_hidden"] = hidden_states[0].numpy().astype(np.float16)
+            out[f"D{D}_T{T}_coeff"] = coeff[0].numpy().astype(np.float16)
+            out[f"D{D}_T{T}_out"] = vertice_out[0].numpy()
+            print("teacher-forced", D, T, tuple(vertice_out.shape), float(vertice_out.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "faceformer_tf.npz"), **out)
 
 
 def gen_flame():
@@ -440,6 +502,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote"):      # regenerate only one fixture
         {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote}[sys.argv[1]]()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "faceformer_tf":
+        gen_faceformer_teacher_forced(import_reference_models()[0])
+        sys.exit(0)
     gen_flame()
     gen_clip_text()
     gen_wav2vec2()
@@ -448,6 +513,7 @@ if __name__ == "__main__":
     gen_masks(ff)
     gen_brain(dp)
     gen_faceformer(ff)
+    gen_faceformer_teacher_forced(ff)
     np.save(os.path.join(HERE, "coeff_mean.npy"), np.load(os.path.join(REF, "misc/coeff_mean.npy")))
     np.save(os.path.join(HERE, "coeff_std.npy"), np.load(os.path.join(REF, "misc/coeff_std.npy")))
     print("done")

@@ -82,3 +82,83 @@ def test_predict_end_to_end(gpu):
     err = (out - ref).abs().max().item()
     print(f"predict end-to-end err {err:.2e}")
     assert out.shape == ref.shape and err < 1e-3
+
+
+@pytest.mark.parametrize("D", [64, 1024])
+@pytest.mark.parametrize("T", [49, 250])
+def test_teacher_forced_matches_reference_golden(gpu, D, T):
+    """HIP teacher-forced pass against the statements of models/faceformer.py:382-391 executed on the reference's own
+    submodules (tests/golden/faceformer_tf.npz): no oracle in between."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    g = np.load(os.path.join(G, "faceformer_tf.npz"))
+    std = np.load(os.path.join(G, "coeff_std.npy"))
+    hs = torch.from_numpy(g[f"D{D}_T{T}_hidden"].astype(np.float32))[None]
+    coeff = torch.from_numpy(g[f"D{D}_T{T}_coeff"].astype(np.float32))[None]
+    ref = g[f"D{D}_T{T}_out"]
+    ff = Faceformer(make_faceformer_weights(2, feature_dim=D), period=30, device=gpu)
+    out = ff.forward_teacher_forced(hs.to(gpu), coeff.to(gpu))[0].cpu().numpy()
+    err = np.abs(out - ref).max()            # NORMALISED space (the pass is trained there); un-normalised = err * std
+    print(f"teacher-forced D={D} T={T}: max-abs err vs reference {err:.2e} (un-normalised {np.abs((out - ref) * std).max():.2e})")
+    assert out.shape == ref.shape == (T, 53)
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize("B,T,D,period", [(3, 100, 64, 25), (2, 40, 128, 30), (5, 77, 256, 30), (4, 600, 64, 30),
+                                          (2, 130, 1024, 30), (1, 1, 64, 30)])
+def test_teacher_forced_batched_vs_oracle(gpu, B, T, D, period):
+    """B > 1 (the reference loops over utterances, :376): every utterance equals the oracle's batch-1 pass."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF
+    w = make_faceformer_weights(2, feature_dim=D)
+    g = torch.Generator().manual_seed(61)
+    hs, coeff = torch.randn(B, T, D, generator=g), torch.randn(B, T, 53, generator=g) * 0.7
+    ref = torch.cat([OF.teacher_forced(w, hs[b:b + 1], coeff[b:b + 1], period) for b in range(B)])
+    ff = Faceformer(w, period=period, device=gpu)
+    out = ff.forward_teacher_forced(hs.to(gpu), coeff.to(gpu)).cpu()
+    err = (out - ref).abs().max().item()
+    print(f"teacher-forced B={B} T={T} D={D}: err {err:.2e} scale {ref.std():.2f}")
+    assert out.shape == ref.shape and err < 1e-3
+    # 59-wide dataset rows (exp | jaw | global | cam, data_loader.py:134-142): the pass reads [:53]
+    wide = torch.cat([coeff, torch.randn(B, T, 6, generator=g)], -1)
+    assert torch.equal(ff.forward_teacher_forced(hs.to(gpu), wide.to(gpu)).cpu(), out)
+
+
+def test_teacher_forced_rejects_bad_shapes(gpu):
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    ff = Faceformer(make_faceformer_weights(2, feature_dim=64), period=30, device=gpu)
+    hs = torch.zeros(1, 10, 64, device=gpu)
+    with pytest.raises(ValueError):
+        ff.forward_teacher_forced(hs, torch.zeros(1, 9, 53, device=gpu))
+    with pytest.raises(ValueError):
+        ff.forward_teacher_forced(hs, torch.zeros(1, 10, 50, device=gpu))
+    with pytest.raises(ValueError):                                    # the reference's tables stop at 600 frames
+        ff.forward_teacher_forced(torch.zeros(1, 601, 64, device=gpu), torch.zeros(1, 601, 53, device=gpu))
+
+
+def test_forward_loss_teacher_forced_and_ar(gpu):
+    """Faceformer.forward (coefficient term, :316-415): audio -> memory with frame_num = coefficient length, the
+    teacher-forced pass or the AR loop, then mean squared error * lip_coeff_weight, against the oracle chain."""
+    from avi_talking_amd.weights import make_faceformer_weights, make_wav2vec2_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from oracle import faceformer as OF, wav2vec2 as OW
+    import torch.nn.functional as F
+    wa, w = make_wav2vec2_weights(0), make_faceformer_weights(2, feature_dim=64)
+    g = torch.Generator().manual_seed(5)
+    audio, T = torch.randn(2, 24000, generator=g), 36
+    coeff = torch.randn(2, T, 59, generator=g) * 0.5
+    ff = Faceformer(w, audio_state_dict=wa, period=30, device=gpu)
+    hs = F.linear(OW.forward(wa, audio, frame_num=T), w["audio_feature_map.weight"], w["audio_feature_map.bias"])
+    ref_tf = torch.cat([OF.teacher_forced(w, hs[b:b + 1], coeff[b:b + 1, :, :53], 30) for b in range(2)])
+    loss, pred = ff.forward(audio.to(gpu), coeff.to(gpu), lip_coeff_weight=2.0)
+    ref_loss = ((ref_tf - coeff[..., :53]) ** 2 * 2.0).mean().item()
+    assert (pred.cpu() - ref_tf).abs().max().item() < 1e-3
+    assert abs(loss.item() - ref_loss) < 1e-4 * max(1.0, ref_loss)
+    loss_c, _ = ff.forward(audio.to(gpu), coeff.to(gpu), criterion=torch.nn.MSELoss(reduction="none"), lip_coeff_weight=2.0)
+    assert abs(loss_c.item() - ref_loss) < 1e-4 * max(1.0, ref_loss)
+    ref_ar = OF.predict_cached(w, hs, 30)
+    loss_ar, pred_ar = ff.forward(audio.to(gpu), coeff.to(gpu), teacher_forcing=False)
+    assert (pred_ar.cpu() - ref_ar).abs().max().item() < 1e-3
+    assert abs(loss_ar.item() - ((ref_ar - coeff[..., :53]) ** 2).mean().item()) < 1e-4

@@ -76,6 +76,39 @@ def test_faceformer_predict_matches_reference(D):
     assert np.abs(cached.numpy() - ref).max() < 5e-5
 
 
+@pytest.mark.parametrize("D", [64, 1024])
+@pytest.mark.parametrize("T", [49, 250])
+def test_faceformer_teacher_forced_matches_reference(D, T):
+    """oracle.faceformer.teacher_forced against the statements of models/faceformer.py:382-391 run on the reference's
+    own submodules (tests/golden/faceformer_tf.npz)."""
+    g = _load("faceformer_tf.npz")
+    w = W.make_faceformer_weights(2, feature_dim=D)
+    hs = torch.from_numpy(g[f"D{D}_T{T}_hidden"].astype(np.float32))[None]
+    coeff = torch.from_numpy(g[f"D{D}_T{T}_coeff"].astype(np.float32))[None]
+    ref = g[f"D{D}_T{T}_out"]
+    out = OF.teacher_forced(w, hs, coeff, 30)[0].numpy()
+    assert out.shape == ref.shape == (T, 53)
+    assert np.abs(out - ref).max() < 2e-5
+    # row i depends on coefficients < i only (shift-right + causal mask) and on memory row i only (diagonal mask)
+    c2, h2 = coeff.clone(), hs.clone()
+    c2[:, 20:] += 1.0
+    h2[:, 21:] += 1.0
+    out2 = OF.teacher_forced(w, h2, c2, 30)[0].numpy()
+    assert np.abs(out2[:21] - out[:21]).max() < 1e-6 and np.abs(out2[21:] - out[21:]).max() > 1e-3
+
+
+def test_faceformer_teacher_forced_equals_ar_loop_on_its_own_outputs():
+    """Teacher forcing with the AR loop's own (normalised) outputs as ground truth reproduces them: the two passes of
+    models/faceformer.py:378-409 are the same function of (memory, previous coefficients) once the start token agrees
+    (the AR loop starts from ``obj_embedding``, teacher forcing from ``vertice_map(0)`` = its bias)."""
+    w = dict(W.make_faceformer_weights(2, feature_dim=64))
+    w["obj_embedding"] = w["vertice_map.bias"][None].clone()
+    hs = torch.randn(2, 40, 64, generator=torch.Generator().manual_seed(9))
+    ar = OF.predict_cached(w, hs, 30)
+    tf = OF.teacher_forced(w, hs, ar, 30)
+    assert (tf - ar).abs().max() < 2e-5
+
+
 EMOTE_SHAPES = {"a": (2, 250), "b": (1, 61), "c": (3, 8)}
 
 
