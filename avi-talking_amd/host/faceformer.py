@@ -64,7 +64,7 @@ class Faceformer:
     def __init__(self, state_dict, audio_state_dict=None, period=30, device="cuda", prec=ops.PREC_BF16X3,
                  coeff_mean=None, coeff_std=None, max_seq_len=600):
         self.device = torch.device(device)
-        self.prec = prec
+        self.prec = ops.prec_plan(prec).small           # the decoder's own GEMMs are fp32-operand launches
         self.period = period
         self.max_seq_len = max_seq_len          # reference mask / PPE tables stop at 600 frames (:88,147)
         w = {k: v.detach().to(torch.float32) for k, v in state_dict.items()}

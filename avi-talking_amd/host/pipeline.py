@@ -26,11 +26,12 @@ from .talking_head import TalkingHeadWrapper
 class SamplingPipeline:
     def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None):
         self.device = torch.device(device)
-        self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=prec, joint_norm=joint_norm)
-        # the opt-in fp16 mode also stores the sampler's attention matrices as one fp16 plane
+        self.plan = plan = ops.prec_plan(prec)       # AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan
+        self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=plan, joint_norm=joint_norm)
+        # the uniform fp16 mode also stores the sampler's attention matrices as one fp16 plane (the mixed plans leave the
+        # sampler as it is in the default mode)
         self.prior = InstructDiffusionPrior.from_state_dict(
-            prior_sd, device=device, prec=ops.fp32_operand_prec(prec),
-            attn_fp16=True if (prec & 0xff) == ops.PREC_F16X2 else None)
+            prior_sd, device=device, prec=plan.small, attn_fp16=True if plan.sampler_all_fp16 else None)
         # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
         self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=self.device, priority=-1)
         self.prior.time_table()          # built once, outside any capture

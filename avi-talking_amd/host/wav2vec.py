@@ -34,12 +34,11 @@ class Wav2Vec2Model:
 
     def __init__(self, state_dict, device="cuda", prec=ops.PREC_BF16X3, length_mode="int"):
         self.device = torch.device(device)
-        # prec = PREC_F16X2 (opt-in): the plane-operand GEMMs (conv layers 1-6, the encoder's projections: 98 % of the
-        # FLOPs) run the 2-term fp16 mode on fp16 hi/lo planes; the small fp32-operand GEMMs (feature projection,
-        # pos-conv) stay on the 3-term bf16 split
-        self.prec_planes = prec
-        self.fmt = ops.plane_fmt(prec)
-        self.prec = prec = ops.PREC_BF16X3 if (prec & 0xff) == ops.PREC_F16X2 else prec
+        # prec: an AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan: one precision per group of plane-operand
+        # GEMMs (conv layers 1-6 | q/k/v/out | ffn: 98 % of the FLOPs).  A 2-term fp16 group (PREC_F16X2) reads fp16 hi/lo
+        # planes and one fp16 weight plane; the small fp32-operand GEMMs (feature projection, pos-conv) stay on the 3-term bf16 split
+        self.plan = plan = ops.prec_plan(prec)
+        self.prec = prec = plan.small
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
         # Activation format.  Conv stack: bf16 hi/lo planes feeding the 256x256 ping-pong GEMM (gemm_pp.hip), each
         # layer's epilogue emitting the next layer's planes (AVI_W2V_PLANES=0: fp32 activations + gemm.hip).
@@ -107,10 +106,11 @@ class Wav2Vec2Model:
             for pw, k, s in zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:]):
                 h = ops.conv1d_cl(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec)
             return h
-        h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b, fmt=self.fmt)
+        pc = self.plan.conv
+        h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b, fmt=ops.plane_fmt(pc))
         n = len(self.convs)
         for i, (pw, k, s) in enumerate(zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:])):
-            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=self.prec_planes, out_planes=i + 1 < n)
+            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=pc, out_planes=i + 1 < n)
         return h
 
     def output_length(self, L50, frame_num=None):
@@ -149,17 +149,18 @@ class Wav2Vec2Model:
                 h = ops.layernorm(h, *ly.ln2, out=h)
             return h
         # LayerNorm outputs feed a big GEMM (qkv / ffn1) AND the residual: emitted as split planes + fp32
-        P, F = self.prec_planes, self.fmt
-        h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=F)
+        PA, PF = self.plan.attn, self.plan.ffn               # every producer writes the format its consumer reads
+        FA, FF = ops.plane_fmt(PA), ops.plane_fmt(PF)
+        h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=FA)
         d = HIDDEN // HEADS
-        for ly in self.layers:   # every projection on the 128x192 ping-pong GEMM, every activation split once
-            qkv = ops.linear_planes(hp_, ly.qkv, prec=P)                              # (B,T,2304) fp32
-            att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5, fmt=F)             # planes
-            h = ops.linear_planes(att, ly.out, residual=h, prec=P)
-            h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h, fmt=F)
-            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=P, out_planes=True)
-            h = ops.linear_planes(f, ly.ff2, residual=h, prec=P)
-            h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=F)
+        for ly in self.layers:   # every projection on the ping-pong GEMMs, every activation split once
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=PA)                             # (B,T,2304) fp32
+            att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5, fmt=FA)            # planes
+            h = ops.linear_planes(att, ly.out, residual=h, prec=PA)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h, fmt=FF)
+            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=PF, out_planes=True)
+            h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF)
+            h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=FA)
         return h
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,

@@ -12,10 +12,48 @@ from .lib import (ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT
                   PLANES_F16, PREC_BF16, PREC_BF16X3, PREC_F16X2)
 
 
+class PrecPlan:
+    """Precision per GEMM group of the audio encoder.  One ``AVI_PREC_*`` value per group: ``conv`` = conv layers 1-6
+    (half of the path's FLOPs), ``attn`` = q/k/v and out projections, ``ffn`` = the two feed-forward matrices; ``small`` =
+    the fp32-operand GEMMs (feature projection, heads, aligner).  Every producer emits its planes in the format its
+    consumer's precision reads (``plane_fmt``), and the groups meet in fp32 (the last conv layer's output, the residual
+    stream), so any combination is consistent."""
+
+    def __init__(self, name, conv, attn, ffn, small=None, sampler_all_fp16=False):
+        self.name, self.conv, self.attn, self.ffn = name, conv, attn, ffn
+        self.small = small if small is not None else PREC_BF16X3
+        self.sampler_all_fp16 = sampler_all_fp16
+
+    def __repr__(self):
+        return f"PrecPlan({self.name}: conv={self.conv:#x} attn={self.attn:#x} ffn={self.ffn:#x} small={self.small:#x})"
+
+
+def prec_plan(prec):
+    """int ``PREC_*`` -> the uniform plan of that precision; "mixed" -> 2-term fp16 conv layers under 3-term bf16
+    transformer projections (measured sensitivities of the coefficients to one fp16 weight plane: conv 2e-4, ffn 2.7e-4,
+    q/k/v/out 5e-4); "mixed_ffn" -> conv and ffn 2-term, q/k/v/out 3-term; a PrecPlan passes through."""
+    if isinstance(prec, PrecPlan):
+        return prec
+    if isinstance(prec, str):
+        named = {"bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16x2": PREC_F16X2}
+        if prec in named:
+            prec = named[prec]
+        elif prec == "mixed":
+            return PrecPlan("mixed", PREC_F16X2, PREC_BF16X3, PREC_BF16X3)
+        elif prec == "mixed_ffn":
+            return PrecPlan("mixed_ffn", PREC_F16X2, PREC_BF16X3, PREC_F16X2)
+        else:
+            raise ValueError(f"unknown precision {prec!r}")
+    base = prec & 0xff
+    if base == PREC_F16X2:
+        return PrecPlan("f16x2", prec, prec, prec, PREC_BF16X3, sampler_all_fp16=True)
+    return PrecPlan({PREC_BF16X3: "bf16x3", PREC_BF16: "bf16"}.get(base, hex(prec)), prec, prec, prec, prec)
+
+
 def fp32_operand_prec(prec):
-    """Precision of the small fp32-operand GEMMs (gemm.hip) under a pipeline precision: the opt-in fp16 mode exists on
+    """Precision of the small fp32-operand GEMMs (gemm.hip) under a pipeline precision: the 2-term fp16 mode exists on
     the plane-operand kernels only, everything else stays on the 3-term bf16 split."""
-    return PREC_BF16X3 if (prec & 0xff) == PREC_F16X2 else prec
+    return prec_plan(prec).small
 
 
 def plane_fmt(prec):

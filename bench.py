@@ -140,9 +140,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # 0.6 s of timed region: the clock settles within the first passes
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2"], default="bf16x3",
-                    help="bf16x3 = 3-term split bf16 MFMA (2e-5 on the coefficients; default and headline); f16x2 = opt-in "
-                         "2-term fp16 (6e-4, inside the 1e-3 gate); bf16 = 1 term (fails the gate)")
+    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2", "mixed", "mixed_ffn"], default="bf16x3",
+                    help="bf16x3 = 3-term split bf16 MFMA (2e-5 on the coefficients; default and headline); mixed = conv layers "
+                         "1-6 in 2-term fp16, transformer projections 3-term bf16; mixed_ffn = conv and ffn 2-term, q/k/v/out "
+                         "3-term; f16x2 = every plane-operand GEMM and the sampler 2-term fp16 (6e-4, inside the 1e-3 gate); "
+                         "bf16 = 1 term (fails the gate)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="replay the pass as ONE graph, passes strictly one after the other (default: two graphs on two "
@@ -189,7 +191,7 @@ def main():
     from avi_talking_amd import ops, weights as W
     from avi_talking_amd.host.pipeline import SamplingPipeline
 
-    prec = {"bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16, "f16x2": ops.PREC_F16X2}[args.prec]
+    prec = ops.prec_plan(args.prec)
     wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
     pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=prec, joint_norm=args.joint_norm)
     pcm = synth_audio(B_CLIPS, N_SAMPLES, 1234 + rank).to(dev)
@@ -281,7 +283,7 @@ def main():
             line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if not args.no_roofline:
-        run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, prec, line["ms_per_step"]))
+        run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, line["ms_per_step"]))
     if world == 1 and not args.no_cpu_baseline:
         run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
     ref_out = {k: out[k].clone() for k in ("predicted_exp", "predicted_jaw")}
@@ -409,7 +411,7 @@ def gemm_family(kw):
     """Which kernel avi_gemm dispatches a launch to (mirrors csrc/gemm.hip avi_gemm)."""
     if kw.get("Ahi"):
         from avi_talking_amd import ops
-        kt = 32 if (kw.get("prec", 3) & 0xff) == 3 else 64
+        kt = 64 if (kw.get("prec", 3) & 0xff) == 1 else 32
         M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
         cus = ops.CU_BUDGET if 0 < ops.CU_BUDGET <= 256 else 256
 
@@ -444,53 +446,112 @@ def gemm_family(kw):
     return f"gemm_kernel<64, {ns}, 128>"
 
 
-def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
+NS_OF_PREC = {1: 1, 2: 2, 3: 3}                     # MFMAs per product: AVI_PREC_BF16 / F16X2 / BF16X3
+PREC_NAME = {1: "bf16", 2: "f16x2", 3: "bf16x3"}
+
+
+def latest_profile(stem):
+    """profiles/rNN_<stem>: the newest round's file."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}")))
+    return c[-1] if c else None
+
+
+def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
     """Per-launch HIP-event timing, on the stream each kernel is launched on, of the kernels that make up the step:
-    every GEMM launch (launch stream) and the one-launch DDPM sampler (side stream, concurrent with the audio branch
-    as in the timed region), over `reps` eager passes of the same workload.
-      GEMM families: achieved = algorithmic FLOPs (2*M*N*K*batch per launch) / summed launch durations; in bf16x3 mode
-        each algorithmic FLOP costs three MFMA FLOPs (`mfma_issued_frac`).
-      Sampler: achieved = bytes of weight planes every workgroup streams through its CU (planes x DDPM steps x
-        workgroups; served by L2 / Infinity Cache, hence above the HBM-side `traffic`) / launch duration.
+    every GEMM launch, the other launches of the audio branch that take >= 2 % of the step (conv layer 0, positional conv,
+    encoder attention, LayerNorm; launch stream) and the one-launch DDPM sampler (side stream, concurrent with the audio
+    branch as in the timed region), over `reps` eager passes of the same workload.
+      GEMM families (kernel x precision): achieved = algorithmic FLOPs (2*M*N*K*batch per launch) / summed launch
+        durations; each algorithmic FLOP costs `mfma_per_product` MFMA FLOPs (`mfma_issued_frac`).
+      Attention / positional conv: algorithmic FLOPs of the launch / duration (MFMA bound; bf16x3 = 3 MFMA per product).
+      conv layer 0, LayerNorm: algorithmic bytes (input read + every output written once) / duration (HBM bound).
+      Sampler: bytes of weight planes every workgroup streams through its CU (planes x DDPM steps x workgroups; served
+        by L2 / Infinity Cache, hence above the HBM-side `traffic`) / launch duration.
     The `roofline` object is the family with the largest time per step ON THE BRANCH THAT BOUNDS THE STEP (`frac_of_step` =
     its time / the measured step; the sampler runs BESIDE the audio branch and leads only when its launch fills the
-    step), `others` the rest.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes under profiles/."""
+    step), `others` the rest; `audio_branch_ms_accounted` = the sum over the audio branch's entries.  `traffic` = HBM
+    bytes per launch and `mfma_busy_pmc` from the newest rocprofv3 PMC passes under profiles/."""
     from avi_talking_amd import ops
     rec, srec = [], []
-    orig = ops.gemm_raw
     prior = pipe.prior
     orig_sample = prior.p_sample_loop
+    saved = {}
 
-    def timed(**kw):
+    def ev_pair():
         s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
-        orig(**kw)
-        e1.record(s)
-        rec.append((gemm_family(kw), e0, e1, 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1)))
+        return s, e0, e1
+
+    def wrap(name, work):
+        """work(args, kwargs, result) -> (family, bound, units: FLOPs or bytes, mfma per product or None)"""
+        fn = saved[name] = getattr(ops, name)
+
+        def timed(*a, **kw):
+            s, e0, e1 = ev_pair()
+            out = fn(*a, **kw)
+            e1.record(s)
+            rec.append((e0, e1) + work(a, kw, out))
+            return out
+        setattr(ops, name, timed)
+
+    def gemm_work(a, kw, out):
+        p = kw.get("prec", 3) & 0xff
+        return (f"{gemm_family(kw)} [{PREC_NAME[p]}]", "mfma", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1),
+                NS_OF_PREC[p])
+
+    def attn_work(a, kw, out):
+        qkv, H = a[0], a[1]
+        B, T, _ = qkv.shape
+        return ("attn_fused_kernel<64> (encoder attention, softmax on the vector pipe)", "mfma", 4.0 * B * H * T * T * 64, 3)
+
+    def posconv_work(a, kw, out):
+        x, groups, taps = a[0], a[3], a[4]
+        B, T, C_ = x.shape
+        return ("posconv_kernel (grouped k=128 conv + bias + GELU + residual)", "mfma",
+                2.0 * B * T * C_ * taps * (C_ // groups), 3)
+
+    def conv0_work(a, kw, out):
+        x = a[0]
+        return ("conv0 (stats + moments + conv layer 0 / GroupNorm / GELU -> planes)", "hbm",
+                float(x.numel() * 4 + out.hi.numel() * 4), None)
+
+    def ln_work(a, kw, out):
+        x = a[0]
+        n = x.numel()
+        return ("layernorm_kernel (fp32 in; fp32 + planes out)", "hbm", float(n * (4 + 4 + (4 if kw.get("want_f32", True) else 0))), None)
+
+    def interp_work(a, kw, out):
+        x = a[0]
+        nin = x.numel() if torch.is_tensor(x) else x.hi.numel()
+        return ("interp_ln_kernel (50 -> 25 Hz + LayerNorm)", "hbm", float(nin * 4 + out.numel() * 4), None)
 
     def timed_sample(*a, **kw):
-        s = torch.cuda.current_stream()              # the pipeline's side stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(s)
+        s, e0, e1 = ev_pair()                        # the pipeline's side stream
         out = orig_sample(*a, **kw)
         e1.record(s)
         srec.append((e0, e1))
         return out
 
-    ops.gemm_raw = timed
-    prior.p_sample_loop = timed_sample
     marks = []
     try:
+        wrap("gemm_raw", gemm_work)
+        wrap("attention_d64_planes", attn_work)
+        wrap("posconv_gelu_residual", posconv_work)
+        wrap("conv0_gn_gelu_planes", conv0_work)
+        wrap("layernorm_planes", ln_work)
+        wrap("interp_layernorm", interp_work)
+        prior.p_sample_loop = timed_sample
         for _ in range(reps + 1):      # pass 0 lets the host run ahead of the device and is dropped
             marks.append(len(rec))
             pipe.run(pcm, voxel, noise)
         torch.cuda.synchronize()
     finally:
-        ops.gemm_raw = orig
+        for name, fn in saved.items():
+            setattr(ops, name, fn)
         prior.p_sample_loop = orig_sample
     marks.append(len(rec))
-    ns = 3 if prec == ops.PREC_BF16X3 else 1
     # every pass issues the same launches in the same order: a launch slot's duration is the MINIMUM over the kept
     # passes, so a host hiccup between recording e0 and enqueueing the kernel (eager mode) cannot inflate a family
     per_pass = [rec[marks[i]:marks[i + 1]] for i in range(1, reps + 1)]
@@ -499,63 +560,76 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         raise RuntimeError("the eager passes issued different launch sequences")
     fam = {}
     for slot in range(n_slots):
-        name, _, _, fl = per_pass[0][slot]
-        ms = min(p_[slot][1].elapsed_time(p_[slot][2]) for p_ in per_pass)
-        f = fam.setdefault(name, [0.0, 0.0, 0])
-        f[0] += ms * reps
-        f[1] += fl * reps
-        f[2] += reps
-    traffic = {}
-    tsrc = None
-    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("kernels", {})
-            tsrc = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-            break
+        _, _, name, bound, units, ns = per_pass[0][slot]
+        ms = min(p_[slot][0].elapsed_time(p_[slot][1]) for p_ in per_pass)
+        f = fam.setdefault(name, [0.0, 0.0, 0, bound, ns])
+        f[0] += ms
+        f[1] += units
+        f[2] += 1
 
-    busy = {}
-    bpath = os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")
-    if os.path.exists(bpath):
-        with open(bpath) as fh:
-            busy = json.load(fh).get("kernels", {})
+    def load_kernels(stem):
+        path = latest_profile(stem)
+        if not path:
+            return {}, None
+        with open(path) as fh:
+            return json.load(fh).get("kernels", {}), "profiles/" + os.path.basename(path)
 
-    def pmc_busy(name):
+    traffic, tsrc = load_kernels("pmc_traffic.json")
+    busy, bsrc = load_kernels("pmc_mfma.json")
+
+    def pmc_lookup(table, name, field):
+        """profiles' tables are keyed by the demangled kernel name: match on the kernel's base name and, for the
+        templated GEMMs, on the tile / precision arguments bench.py knows the launch by."""
         base = name.split(" ")[0].split("<")[0]
-        tag = name.split("<")[1].split(">")[0] if "<" in name else ""
-        tag = {"NT=3": ", 3,", "NT=4": ", 4,"}.get(tag, tag)
-        hit = busy.get(name) or next((v for k, v in busy.items() if k.startswith(base) and (tag in k if tag else True)), None)
-        return hit["mfma_busy_frac"] if hit else None
+        want = []
+        if "NT=3" in name:
+            want.append(", 3,")
+        if "NT=4" in name:
+            want.append(", 4,")
+        if name.startswith("gemm_kernel<"):
+            want.append(name.split(" ")[0].split("<")[1].rstrip(">"))
+        f16 = "[f16x2]" in name
+        for k, v in table.items():
+            if not k.startswith(base):
+                continue
+            if any(w_ not in k + "," for w_ in want):
+                continue
+            if base.startswith("gemm_pp") and (("true" in k) != f16):
+                continue
+            return v.get(field)
+        return None
 
     _B = voxel.shape[0]
     _spg = max(1, min(prior.samples_per_group, _B)) if prior.samples_per_group > 0 else 1
     sampler_cus = -(-_B // _spg)
 
     def describe(name):
-        ms, fl, n = fam[name]
-        ach = fl / (ms * 1e-3) / 1e12
-        t = traffic.get(name)                       # fp32-operand kernels carry their exact kernel name
-        if t is None:
-            base = name.split(" ")[0].split("<")[0]
-            tag = name.split("<")[1].split(">")[0] if "<" in name else ""
-            tag = {"NT=3": ", 3>", "NT=4": ", 4>"}.get(tag, tag)
-            t = next((v for k, v in traffic.items() if k.startswith(base) and (tag in k if tag else True)), None)
-        return {"bound": "mfma", "kernel": f"{name} (bf16 MFMA 16x16x32, {ns} MFMA per product)",
-                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),
-                # inside the pass the sampler's workgroups hold `sampler_cus` of the 256 CUs: the same rate against the
-                # matrix-core peak of the CUs the GEMMs can actually run on
-                "mfma_issued_frac_of_free_cus": round(ach * ns / (PEAK_BF16_TFLOPS * (256 - sampler_cus) / 256.0), 4),
-                "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
-                "ms_per_step": round(ms / reps, 3), "frac_of_step": round(ms / reps / step_ms, 3),
-                "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
-                "traffic": t["hbm_bytes_per_launch"] if t else None,
-                # matrix-pipe busy cycles / (kernel cycles x 1024 SIMDs), rocprofv3 PMC pass (kernels serialised by the
-                # profiler, i.e. the kernel alone on the chip): profiles/r02_pmc_mfma.json
-                "mfma_busy_pmc": pmc_busy(name)}
+        ms, units, n, bound, ns = fam[name]
+        e = {"bound": bound, "kernel": name, "launches_per_step": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+             "ms_per_step": round(ms, 3), "frac_of_step": round(ms / step_ms, 3),
+             "traffic": pmc_lookup(traffic, name, "hbm_bytes_per_launch")}
+        if bound == "mfma":
+            ach = units / (ms * 1e-3) / 1e12
+            e.update({"kernel": f"{name} (MFMA 16x16x32, {ns} MFMA per product)", "achieved": round(ach, 1),
+                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                      "mfma_per_product": ns, "mfma_issued_frac": round(ach * ns / PEAK_BF16_TFLOPS, 4),
+                      # inside the pass the sampler's workgroups hold `sampler_cus` of the 256 CUs: the same rate against
+                      # the matrix-core peak of the CUs the audio branch can actually run on
+                      "mfma_issued_frac_of_free_cus": round(ach * ns / (PEAK_BF16_TFLOPS * (256 - sampler_cus) / 256.0), 4),
+                      "algorithmic_gflop_per_step": round(units / 1e9, 1),
+                      # matrix-pipe busy cycles / (kernel cycles x 1024 SIMDs), rocprofv3 PMC pass (kernels serialised by
+                      # the profiler, i.e. the kernel alone on the chip)
+                      "mfma_busy_pmc": pmc_lookup(busy, name, "mfma_busy_frac")})
+        else:
+            gbps = units / (ms * 1e-3) / 1e9
+            e.update({"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+                      "algorithmic_bytes_per_launch": int(units / n)})
+            if name.startswith("layernorm"):
+                e["note"] = "operands were just written by the producing GEMM: served by L2 / Infinity Cache"
+        return e
 
     entries = [describe(k) for k in fam]
+    audio_ms = round(sum(e["ms_per_step"] for e in entries), 3)
     if srec:
         B = voxel.shape[0]
         sms = min(a.elapsed_time(b) for a, b in srec[1:])
@@ -565,7 +639,6 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         plane_bytes = sum(t.numel() * t.element_size() for t in prior.net._packs)
         T = prior.noise_scheduler.num_timesteps
         nbytes = plane_bytes * T * groups
-        t = next((v for k, v in traffic.items() if k.startswith("prior_sample")), None)
         entries.append({
             "bound": "hbm", "bound_detail": "weights re-streamed L2 -> CU every DDPM step (per-CU ingest, served by L2 / "
                                             "Infinity Cache: neither the HBM nor the MFMA roof); latency-bound chain of "
@@ -576,8 +649,8 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
             "launches_per_step": 1, "avg_launch_us": round(sms * 1e3, 1), "ms_per_step": round(sms, 3),
             "frac_of_step": round(sms / step_ms, 3), "algorithmic_bytes_per_launch": nbytes,
             "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
-            "traffic": t["hbm_bytes_per_launch"] if t else None,
-            "mfma_busy_pmc": (next((v for k, v in busy.items() if k.startswith("prior_sample")), {}) or {}).get("mfma_busy_frac")})
+            "traffic": pmc_lookup(traffic, "prior_sample", "hbm_bytes_per_launch"),
+            "mfma_busy_pmc": pmc_lookup(busy, "prior_sample", "mfma_busy_frac")})
     # Order: time per step.  The sampler runs BESIDE the audio branch: it leads only when its launch fills the step (it then
     # bounds it: >= 95 %); with slack it is listed second, behind the dominant family of the branch that does bound the step.
     smp = [e for e in entries if e["kernel"].startswith("prior sampler")]
@@ -589,8 +662,8 @@ def measure_roofline(pipe, pcm, voxel, noise, prec, step_ms, reps=3):
         entries.insert(0 if bounds else 1, smp[0])
     out = entries[0]
     out["others"] = entries[1:]
-    if tsrc:
-        out["traffic_source"] = tsrc
+    out["audio_branch_ms_accounted"] = audio_ms
+    out["pmc_sources"] = [x for x in (tsrc, bsrc) if x]
     return out
 
 

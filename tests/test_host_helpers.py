@@ -125,3 +125,14 @@ def test_draw_noise_call_order_matches_reference_loop():
     for _ in range(100):
         ref.append(torch.randn(torch.Size((3, 1, 128)), dtype=torch.float32, generator=g))   # p_sample noise
     assert out.shape == (101, 3, 1, 128) and torch.equal(out, torch.stack(ref))
+
+
+def test_precision_plans_resolve():
+    import pytest
+    from avi_talking_amd import ops
+    for name, conv, attn, ffn in (("bf16x3", 3, 3, 3), ("mixed", 2, 3, 3), ("mixed_ffn", 2, 3, 2), ("f16x2", 2, 2, 2)):
+        p = ops.prec_plan(name)
+        assert (p.conv, p.attn, p.ffn, p.small) == (conv, attn, ffn, 3) and ops.prec_plan(p) is p
+    assert ops.prec_plan(ops.PREC_F16X2).sampler_all_fp16 and not ops.prec_plan("mixed").sampler_all_fp16
+    with pytest.raises(ValueError):
+        ops.prec_plan("fp8")
