@@ -33,14 +33,14 @@ static inline void zero_doubles(double* p, int n, hipStream_t s) {
 // ------------------------------------------------------------------ audio zero-mean / unit-var
 // stats[2*s + {0,1}] = sum, sum of squares (double) of clip s (s = 0 when joint).
 template <bool I16>
-__global__ __launch_bounds__(256) void audio_stats_kernel(const void* __restrict__ pcm, int N, int joint,
+__global__ __launch_bounds__(256) void audio_stats_kernel(const void* __restrict__ pcm, int N, int joint, int vec16,
                                                            double* __restrict__ stats) {
     __shared__ double red[2][4];
     const int b = blockIdx.y;
     const long long base = (long long)b * N;
     double s = 0.0, q = 0.0;
     const int vec = I16 ? 8 : 4;                              // samples per 16-byte load
-    if ((N % vec) == 0) {                                     // every clip starts on a 16-byte boundary
+    if (vec16) {                   // host-checked: the base pointer and every clip start (N % vec == 0) are 16-byte aligned
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * vec; i < N; i += gridDim.x * blockDim.x * vec) {
             float x[8];
             if (I16) {
@@ -588,11 +588,13 @@ extern "C" int avi_audio_normalize(const void* pcm, int is_int16, int B, int N, 
     zero_doubles(stats, 2 * B, s);
     dim3 sgrid(grid_for(N / 8, 256, 32), B); // up to 32 workgroups per clip (16-byte loads): 64 atomics per clip
     dim3 grid(grid_for(N, 256, 64), B);
+    // 16-byte loads only when the buffer allows them (a pointer taken from an offset view need not be aligned)
+    const int vec16 = ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0) && (N % (is_int16 ? 8 : 4)) == 0;
     if (is_int16) {
-        hipLaunchKernelGGL(audio_stats_kernel<true>, sgrid, dim3(256), 0, s, pcm, N, joint, stats);
+        hipLaunchKernelGGL(audio_stats_kernel<true>, sgrid, dim3(256), 0, s, pcm, N, joint, vec16, stats);
         hipLaunchKernelGGL(audio_apply_kernel<true>, grid, dim3(256), 0, s, pcm, N, B, joint, eps, stats, out);
     } else {
-        hipLaunchKernelGGL(audio_stats_kernel<false>, sgrid, dim3(256), 0, s, pcm, N, joint, stats);
+        hipLaunchKernelGGL(audio_stats_kernel<false>, sgrid, dim3(256), 0, s, pcm, N, joint, vec16, stats);
         hipLaunchKernelGGL(audio_apply_kernel<false>, grid, dim3(256), 0, s, pcm, N, B, joint, eps, stats, out);
     }
     return avi_launch_status();

@@ -158,6 +158,11 @@ extern "C" int avi_posconv_gelu_residual(const float* x, int B, int T, int C, in
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) |
          reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_lo)) & 15)
         return AVI_EINVAL;
+    {   // not in place: a workgroup reads a +/-64-frame halo of x that its neighbours are storing as out
+        const uintptr_t xa = reinterpret_cast<uintptr_t>(x), oa = reinterpret_cast<uintptr_t>(out);
+        const uintptr_t nbytes = (uintptr_t)B * T * C * sizeof(float);
+        if (xa < oa + nbytes && oa < xa + nbytes) return AVI_EINVAL;
+    }
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(posconv_kernel), SMEM_BYTES);
     hipLaunchKernelGGL(posconv_kernel, dim3((T + BMP - 1) / BMP, groups, B), dim3(NTHR), SMEM_BYTES,

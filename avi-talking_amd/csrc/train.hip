@@ -709,6 +709,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         lr = dyn[0];
         bc1 = dyn[1];
         rsqrt_bc2 = dyn[2];
+        if (dyn[3] > 0.f) b1 = dyn[3];   // this step's beta1 (OneCycleLR cycle_momentum); 0 = the argument's
     }
     const long long nv = n >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {

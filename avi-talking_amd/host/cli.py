@@ -153,7 +153,12 @@ def run_train(args):
     tr = PriorTrainer(sd, device=dev, lr=args.max_lr)
     names = [n for n in _layout() if n in sd]
     epoch0 = CK.resume_ckpt(args.ckpt_path, tr, names) if (args.resume_from_ckpt and args.ckpt_path) else 0
+    # the fused trainer's GEMM tiles take batches that are multiples of 64 rows (PriorTrainer: "training batch rows must be a
+    # multiple of 64"); the reference's --batch_size default is 1 and its script passes 256
     B = max(args.batch_size, 64) // 64 * 64
+    if B != args.batch_size:
+        print(f"note: --batch_size {args.batch_size} -> effective batch {B} (the HIP trainer needs multiples of 64 rows); "
+              f"the schedule length follows --synthetic_steps ({args.synthetic_steps} steps per epoch) as given")
     steps = args.synthetic_steps
     sched = reference_schedule(args.max_lr, args.max_epoch, steps)
     temps = cosine_anneal(0.004, 0.0075, max(args.max_epoch, 1))        # soft_loss_temps (:375)
@@ -164,8 +169,10 @@ def run_train(args):
         for it in range(steps):
             voxel = torch.randn(B, 768, device=dev, generator=g)
             target = torch.randn(B, 1, 128, device=dev, generator=g) * 0.3
-            lr = sched.lr_at(min(sched.last_step, sched.total_steps - 1))
-            out = tr.train_step(voxel, target, temps[min(epoch, len(temps) - 1)], rand=tr.draw(B, generator=g), lr=lr)
+            k = min(sched.last_step, sched.total_steps - 1)
+            lr = sched.lr_at(k)                # OneCycleLR moves the rate AND AdamW's beta1 (cycle_momentum, :351-357)
+            out = tr.train_step(voxel, target, temps[min(epoch, len(temps) - 1)], rand=tr.draw(B, generator=g), lr=lr,
+                                beta1=sched.momentum_at(k))
             sched.step()
             if it % args.log_loss_steps == 0:
                 lp, ln = float(out["loss_prior"].item()), float(out["loss_nce"].item())

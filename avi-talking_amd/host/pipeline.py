@@ -23,6 +23,29 @@ from .diffusion_prior import InstructDiffusionPrior
 from .talking_head import TalkingHeadWrapper
 
 
+# Streams are a per-DEVICE resource here, not a per-object one.  HIP multiplexes streams onto a few in-order hardware queues
+# and which queue a stream gets depends on how many streams the process has created before it: a second pipeline object
+# that made its own side stream and its own pool of candidate streams got a different (worse) queue assignment than the
+# first and replayed 10-30 % slower in the same process (round 2: 13.0-14.9 vs 11.0 ms for the same graphs in a fresh
+# process).  Every pipeline of a device therefore shares ONE high-priority side stream, ONE pool of replay streams and the
+# (body, head) pair chosen from it by the first capture_pipelined() on that device.
+_DEVICE_STREAMS = {}
+
+
+def device_streams(device):
+    """{'side': high-priority stream of the sampler's branch, 'pool': candidate replay streams, 'pick': index of the head's
+    stream in the pool (None until the first capture_pipelined on the device has timed the candidates)}."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        st = _DEVICE_STREAMS[key] = {
+            # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
+            "side": torch.cuda.Stream(device=device, priority=-1),
+            "pool": [torch.cuda.Stream(device=device) for _ in range(5)], "pick": None, "timings_ms": None}
+    return st
+
+
 class SamplingPipeline:
     def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None):
         self.device = torch.device(device)
@@ -32,8 +55,7 @@ class SamplingPipeline:
         # sampler as it is in the default mode)
         self.prior = InstructDiffusionPrior.from_state_dict(
             prior_sd, device=device, prec=plan.small, attn_fp16=True if plan.sampler_all_fp16 else None)
-        # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
-        self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=self.device, priority=-1)
+        self.side = side_stream if side_stream is not None else device_streams(self.device)["side"]
         self.prior.time_table()          # built once, outside any capture
         self._graph = None
         self._static = None
@@ -73,11 +95,9 @@ class SamplingPipeline:
         # the sampler's workgroups (one per samples_per_group samples) hold a CU each until the join: GEMM tile shapes of the
         # audio branch are chosen for the CUs that remain (avi_talking.h AviGemm.cus)
         spg = max(1, min(self.prior.samples_per_group, B))
-        ops.CU_BUDGET = 256 - (B + spg - 1) // spg if self.prior.samples_per_group > 0 else 256 - B
-        try:
-            sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B})
-        finally:
-            ops.CU_BUDGET = 0
+        free_cus = 256 - (B + spg - 1) // spg if self.prior.samples_per_group > 0 else 256 - B
+        sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B},
+                                                 cus=free_cus)
         # 3. join
         cur.wait_stream(self.side)
         return sample["audio_feature"], style
@@ -148,34 +168,49 @@ class SamplingPipeline:
         torch.cuda.synchronize(dev)
         return self
 
-    def _pick_streams(self, candidates=4, replays=4):
+    def _pick_streams(self, replays=4):
         """HIP multiplexes streams onto a few IN-ORDER hardware queues, and which queue a stream gets is not ours to choose:
         with the head's stream on the body's queue the head runs between two bodies instead of beside the next one
         (+0.5 ms per pass in the kernel trace; with the aligner as a third graph it was the aligner, +0.19 ms).  The
-        graphs do not care which stream replays them, so a few (body, head) stream pairs - taken from torch's pool with
-        0, 1, 2, ... unused streams in between - are TIMED over a few replays and the fastest is kept
-        (scripts/pass_timeline.py --gap shows the queue of every launch in the hand-over)."""
+        graphs do not care which stream replays them, so the (body, head) pairs of the device's stream pool are TIMED
+        over a few replays ONCE PER DEVICE, the fastest is kept in ``device_streams(device)`` and every later capture
+        on the device - this object's or another's - reuses it without measuring again: the choice is deterministic for
+        the life of the process and visible as ``self.stream_choice`` (scripts/pass_timeline.py --gap shows the queue of
+        every launch in the hand-over)."""
         import time
         dev = self.device
-        pool = [torch.cuda.Stream(device=dev) for _ in range(candidates + 1)]
-        best = None
-        for k in range(1, candidates + 1):
-            self._s_body, self._s_head = pool[0], pool[k]
-            self.replay_pipelined()
-            torch.cuda.synchronize(dev)
-            t = time.perf_counter()
-            for _ in range(replays):
+        st = device_streams(dev)
+        pool = st["pool"]
+        if st["pick"] is None:
+            timings = []
+            for k in range(1, len(pool)):
+                self._s_body, self._s_head = pool[0], pool[k]
                 self.replay_pipelined()
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t
-            if best is None or dt < best[0]:
-                best = (dt, k)
-        self._streams_kept = pool                      # the unused ones stay alive: their queue slots stay taken
-        self._s_body, self._s_head = pool[0], pool[best[1]]
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(replays):
+                    self.replay_pipelined()
+                torch.cuda.synchronize(dev)
+                timings.append((time.perf_counter() - t) / replays * 1e3)
+            st["pick"] = 1 + min(range(len(timings)), key=timings.__getitem__)
+            st["timings_ms"] = [round(t, 3) for t in timings]
+        self._s_body, self._s_head = pool[0], pool[st["pick"]]
+        self.stream_choice = {"body": 0, "head": st["pick"], "candidate_ms_per_pass": st["timings_ms"]}
 
-    def replay_pipelined(self):
-        """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised)."""
+    def replay_pipelined(self, pcm=None, voxel=None, noise=None):
+        """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised).
+        ``pcm`` / ``voxel`` / ``noise``: the next batch, copied into the static input buffers on the body's stream in front
+        of the replay (same contract as ``replay``; None = keep what the buffer holds).  The copy is ordered behind the
+        previous body by the stream, so a caller may hand over batch k+1 while pass k is still running."""
+        if pcm is not None or voxel is not None or noise is not None:
+            self._s_body.wait_stream(torch.cuda.current_stream(self.device))   # the caller's stream produced the new inputs
         with torch.cuda.stream(self._s_body):
+            for dst, src in zip(self._static, (pcm, voxel, noise)):
+                if src is not None:
+                    if src.shape != dst.shape or src.dtype != dst.dtype:
+                        raise ValueError(f"replay_pipelined: input {tuple(src.shape)} {src.dtype} does not match the "
+                                         f"captured {tuple(dst.shape)} {dst.dtype}")
+                    dst.copy_(src, non_blocking=True)
             self._s_body.wait_event(self._e_taken)       # the previous head has copied the previous body's results
             self._g_body.replay()
             self._e_body.record(self._s_body)

@@ -4,17 +4,22 @@ functions of the step: the fused AdamW takes the learning rate as a per-step arg
 
   * ``OneCycleLR``: ``torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr, total_steps = epochs * len(dl) * 5,
     final_div_factor = 1000, pct_start = 2 / epochs)`` with torch's defaults (cosine annealing, div_factor 25,
-    two phases) - train_diffusion_prior.py:343-357;
+    two phases, ``cycle_momentum=True``: AdamW's beta1 runs 0.95 -> 0.85 while the rate rises and back to 0.95 while it
+    falls) - train_diffusion_prior.py:343-357; ``lr_at(step)`` and ``momentum_at(step)`` are what the optimizer step
+    number ``step`` runs with;
   * ``cosine_anneal`` - train_diffusion_prior.py:122-123 (soft-CLIP temperatures per epoch).
 """
 import math
 
 
 class OneCycleLR:
-    def __init__(self, max_lr, total_steps, pct_start=0.3, div_factor=25.0, final_div_factor=1e4):
+    def __init__(self, max_lr, total_steps, pct_start=0.3, div_factor=25.0, final_div_factor=1e4,
+                 cycle_momentum=True, base_momentum=0.85, max_momentum=0.95):
         if total_steps <= 0:
             raise ValueError("total_steps must be positive")
         self.max_lr, self.total_steps = float(max_lr), int(total_steps)
+        self.cycle_momentum = bool(cycle_momentum)
+        self.base_momentum, self.max_momentum = float(base_momentum), float(max_momentum)
         self.initial_lr = self.max_lr / div_factor
         self.min_lr = self.initial_lr / final_div_factor
         self.up_end = float(pct_start * total_steps) - 1.0          # torch: phase 1 ends at pct_start * total - 1
@@ -32,6 +37,17 @@ class OneCycleLR:
         if step <= self.up_end:
             return self._cos(self.initial_lr, self.max_lr, step / self.up_end)
         return self._cos(self.max_lr, self.min_lr, (step - self.up_end) / (self.down_end - self.up_end))
+
+    def momentum_at(self, step):
+        """AdamW beta1 of optimizer step ``step`` (torch's ``cycle_momentum``: inverse to the rate, same two cosine
+        phases), or None when the scheduler leaves the optimizer's betas alone."""
+        if not self.cycle_momentum:
+            return None
+        if step >= self.total_steps:
+            raise ValueError(f"step {step} beyond total_steps {self.total_steps}")
+        if step <= self.up_end:
+            return self._cos(self.max_momentum, self.base_momentum, step / self.up_end)
+        return self._cos(self.base_momentum, self.max_momentum, (step - self.up_end) / (self.down_end - self.up_end))
 
     def get_last_lr(self):
         return [self.lr_at(self.last_step)]

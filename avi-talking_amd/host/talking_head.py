@@ -187,8 +187,8 @@ class TalkingHeadWrapper:
         self.head = EmoteHead(head_state_dict, device=device, prec=ops.fp32_operand_prec(prec))
         self.joint_norm = joint_norm        # AudioEncoders.py:170-178: HF processor sees ONE (B*L) array
 
-    def forward_audio(self, sample):
-        """Wav2Vec2Encoder._forward (AudioEncoders.py:165-200)."""
+    def forward_audio(self, sample, cus=0):
+        """Wav2Vec2Encoder._forward (AudioEncoders.py:165-200).  ``cus``: compute units free for the big GEMMs (0 = all)."""
         if "raw_audio" in sample:
             raw = sample["raw_audio"].to(self.device)
             B, T = raw.shape[0], raw.shape[1]
@@ -200,7 +200,7 @@ class TalkingHeadWrapper:
         else:
             x = sample["processed_audio"].to(self.device, torch.float32).contiguous()
             T = sample.get("frame_num")
-        out = self.audio_model(x, frame_num=T)
+        out = self.audio_model(x, frame_num=T, cus=cus)
         sample["audio_feature"] = out.last_hidden_state
         return sample
 

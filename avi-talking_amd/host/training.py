@@ -745,20 +745,24 @@ class PriorTrainer:
         scales by 1/world."""
         return self.sync.finish(self.store.G)
 
-    def _set_dyn(self, lr):
-        """Step-dependent AdamW scalars go through device memory so a captured graph can be replayed."""
+    def _set_dyn(self, lr, beta1=None):
+        """Step-dependent AdamW scalars go through device memory so a captured graph can be replayed: the rate, the two
+        bias corrections and this step's beta1 (OneCycleLR cycles it, host/schedule.py; torch forms the first bias
+        correction from the CURRENT beta1: 1 - beta1 ** step)."""
         b1, b2 = self.betas
-        host = torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), 0.0])
+        b1 = b1 if beta1 is None else float(beta1)
+        host = torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), b1])
         self.dyn.copy_(host, non_blocking=True)
 
-    def optimizer_step(self, lr=None, world=1, use_dyn=False, _in_graph=False):
+    def optimizer_step(self, lr=None, world=1, use_dyn=False, _in_graph=False, beta1=None):
         S = self.store
         lr = self.lr if lr is None else lr
         b1, b2 = self.betas
+        b1 = b1 if beta1 is None else float(beta1)
         if not _in_graph:
             self.step_count += 1
             if use_dyn:
-                self._set_dyn(lr)
+                self._set_dyn(lr, b1)
         dyn = self.dyn.data_ptr() if use_dyn else 0
         so = L.load()
         for lo, hi_, wd in ((0, S.n_decay, self.wd), (S.n_decay, S.numel, 0.0)):
@@ -769,12 +773,14 @@ class PriorTrainer:
                                      L.stream_ptr()), "adamw")
         self.refresh()
 
-    def train_step(self, voxel, clip_target, temp, rand=None, lr=None):
+    def train_step(self, voxel, clip_target, temp, rand=None, lr=None, beta1=None):
+        """``lr`` / ``beta1``: this step's rate and AdamW beta1 (``OneCycleLR.lr_at`` / ``momentum_at``); None = the
+        constructor's."""
         rand = rand or self.draw(voxel.shape[0])
         out = self.forward_backward(voxel, clip_target, rand["times"], rand["noise"], temp, rand["brain_keep"],
                                     rand["image_keep"], rand["dropout_masks"])
         world = self.allreduce_grads()
-        self.optimizer_step(lr, world)
+        self.optimizer_step(lr, world, beta1=beta1)
         return out
 
     # ------------------------------------------------------------------ hipGraph capture (single GPU)
@@ -802,8 +808,8 @@ class PriorTrainer:
             self._gout = body(True)
         return self
 
-    def replay_step(self, lr=None):
+    def replay_step(self, lr=None, beta1=None):
         self.step_count += 1
-        self._set_dyn(self.lr if lr is None else lr)
+        self._set_dyn(self.lr if lr is None else lr, beta1)
         self._graph.replay()
         return self._gout

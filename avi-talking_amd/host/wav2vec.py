@@ -97,7 +97,7 @@ class Wav2Vec2Model:
         return self
 
     # ------------------------------------------------------------------ stages
-    def feature_extractor(self, input_values):
+    def feature_extractor(self, input_values, cus=0):
         """(B, N) -> channels-last (B, L, 512) (the reference returns (B, 512, L)).
         Activations between the conv layers travel as split bf16 planes (x = hi + lo): each producer splits once in
         its epilogue and the LDS-DMA GEMM consumes the planes without any conversion in its loop."""
@@ -110,7 +110,7 @@ class Wav2Vec2Model:
         h = ops.conv0_gn_gelu_planes(input_values, self.w0, self.gn_g, self.gn_b, fmt=ops.plane_fmt(pc))
         n = len(self.convs)
         for i, (pw, k, s) in enumerate(zip(self.convs, CONV_KERNEL[1:], CONV_STRIDE[1:])):
-            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=pc, out_planes=i + 1 < n)
+            h = ops.conv1d_cl_planes(h, pw, k, s, act=ops.ACT_GELU, prec=pc, out_planes=i + 1 < n, cus=cus)
         return h
 
     def output_length(self, L50, frame_num=None):
@@ -119,12 +119,12 @@ class Wav2Vec2Model:
         seq_len = L50 / 50.0
         return int(seq_len * 25) if self.length_mode == "int" else int(math.ceil(seq_len * 25))
 
-    def encoder(self, hp):
+    def encoder(self, hp, cus=0):
         B, T, _ = hp.shape
         cg = HIDDEN // POS_G
         if self.posconv_kernel:      # one launch, the input window resident in LDS (csrc/posconv.hip)
             h = ops.posconv_gelu_residual(hp, self.pos, self.pos_bias, POS_G, POS_K, 64)
-            return self._encoder_layers(h)
+            return self._encoder_layers(h, cus)
         xg = ops.group_pad_pack(hp, POS_G, POS_K // 2)
         h = torch.empty_like(hp)
         Tp = T + POS_K
@@ -133,9 +133,9 @@ class Wav2Vec2Model:
                      R=hp.data_ptr(), ldr=HIDDEN, act=ops.ACT_GELU, prec=self.prec, batch=B * POS_G, z_inner=POS_G,
                      sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
                      sR=(T * HIDDEN, cg))
-        return self._encoder_layers(h)
+        return self._encoder_layers(h, cus)
 
-    def _encoder_layers(self, h):
+    def _encoder_layers(self, h, cus=0):
         d = HIDDEN // HEADS
         if not self.use_planes_tf:
             h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
@@ -154,29 +154,30 @@ class Wav2Vec2Model:
         h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=FA)
         d = HIDDEN // HEADS
         for ly in self.layers:   # every projection on the ping-pong GEMMs, every activation split once
-            qkv = ops.linear_planes(hp_, ly.qkv, prec=PA)                             # (B,T,2304) fp32
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=PA, cus=cus)                    # (B,T,2304) fp32
             att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5, fmt=FA)            # planes
-            h = ops.linear_planes(att, ly.out, residual=h, prec=PA)
+            h = ops.linear_planes(att, ly.out, residual=h, prec=PA, cus=cus)
             h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h, fmt=FF)
-            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=PF, out_planes=True)
-            h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF)
+            f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=PF, out_planes=True, cus=cus)
+            h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF, cus=cus)
             h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=FA)
         return h
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, frame_num=None):
+                output_hidden_states=None, return_dict=None, frame_num=None, cus=0):
         """models/lib/wav2vec.py:80-156.  ``attention_mask`` (padding) is not supported on the
-        hot path (the reference callers never pass one: models/faceformer.py:330,673)."""
+        hot path (the reference callers never pass one: models/faceformer.py:330,673).  ``cus`` (not in the reference
+        signature): compute units the big GEMMs may count on, 0 = the whole chip (ops.gemm_raw)."""
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the reference hot path")
         if input_values.dim() != 2:
             raise ValueError("input_values must be (B, N)")
         x = input_values.to(self.device, torch.float32).contiguous()
-        feats = self.feature_extractor(x)
+        feats = self.feature_extractor(x, cus)
         T = self.output_length(feats.shape[1], frame_num)
         h25 = ops.interp_layernorm(feats, T, self.fp_g, self.fp_b)
         hp = ops.linear(h25, self.proj, prec=self.prec)
-        h = self.encoder(hp)
+        h = self.encoder(hp, cus)
         out = SimpleNamespace(last_hidden_state=h, hidden_states=None, attentions=None,
                               extract_features=feats)
         return out if (return_dict is None or return_dict) else (h,)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libavi_talking_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_LRELU02, ACT_RELU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 PREC_BF16, PREC_F16X2, PREC_BF16X3 = 1, 2, 3
+AVI_OK, AVI_EINVAL, AVI_ENOSPC = 0, -1, -2          # status codes of include/avi_talking.h
 PLANES_BF16, PLANES_F16 = 0, 1
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong

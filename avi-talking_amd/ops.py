@@ -68,11 +68,6 @@ def _f32c(t, name):
     return t
 
 
-# Compute units a GEMM launch can count on (0 = all): the sampling pipeline lowers it while the sampler's workgroups
-# hold CUs on the side stream, so that tile shapes fill whole rounds of the CUs that are actually free.
-CU_BUDGET = 0
-
-
 class PackedWeight:
     """A Linear/Conv weight [N][K] pre-split into bf16 hi/lo parts, rows padded for the GEMM tiles."""
 
@@ -110,11 +105,13 @@ class PackedWeight:
 
 def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
              prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0),
-             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0):
-    """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets)."""
+             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0, cus=0):
+    """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets).  ``cus``: compute units the
+    launch can count on (0 = all 256): the sampling pipeline passes what the sampler's resident workgroups leave, so that
+    the plane-operand kernels pick tile shapes that fill whole rounds of the CUs that are actually free (AviGemm.cus)."""
     g = L.AviGemm()
     g.ldw = ldw
-    g.cus = CU_BUDGET
+    g.cus = cus
     g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
     g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
@@ -408,7 +405,7 @@ def conv0_gn_gelu_planes(x, w0, gamma, beta, eps=1e-5, fmt=PLANES_BF16):
     return out
 
 
-def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_planes=True):
+def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_planes=True, cus=0):
     """Channels-last Conv1d (no padding) on split-plane input: the overlapping-row GEMM on the LDS-DMA kernel."""
     B, Tin, Cin = xp.shape
     if pw.K != ksize * Cin or pw.N <= 64:
@@ -426,11 +423,11 @@ def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_
     whi, wlo = pw.planes_for(prec)
     gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=stride * Cin, Whi=whi, Wlo=wlo,
              ldc=pw.N, M=Tout, N=pw.N, K=pw.K, bias=L.ptr(pw.bias), act=act, prec=prec, batch=B, sA=(Tin * Cin, 0),
-             sC=(Tout * pw.N, 0), **c_args)
+             sC=(Tout * pw.N, 0), cus=cus, **c_args)
     return out
 
 
-def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None, out_planes=False):
+def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None, out_planes=False, cus=0):
     """out[..., N] = act(x @ W^T + b) + residual with x given as split planes; the result is fp32, or split planes
     too (``out_planes=True``: a ``Planes`` for the next GEMM)."""
     K = xp.shape[-1]
@@ -452,7 +449,8 @@ def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=Non
         c_args = dict(C_=out.data_ptr())
     whi, wlo = pw.planes_for(prec)
     gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=whi, Wlo=wlo,
-             ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act, prec=prec, **c_args)
+             ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act, prec=prec, cus=cus,
+             **c_args)
     return out
 
 

@@ -54,8 +54,9 @@ def synth_audio(B, N, seed):
     return x.clamp(-32768, 32767).to(torch.int16)
 
 
-def launch_ranks(n, argv, timeout):
-    """`python bench.py --gpus N` without a launcher: spawn N rank processes of this script.  The parent makes no GPU
+def launch_ranks(n, argv, timeout, script=None):
+    """`python bench.py --gpus N` without a launcher: spawn N rank processes of this script (`script`: another program to
+    run as the ranks - the launcher's own tests).  The parent makes no GPU
     call (a process that has initialised the GPU must not be replaced or forked), waits for all children, kills the
     others by PID when one fails or the timeout expires, and returns the worst exit code."""
     import socket
@@ -66,9 +67,12 @@ def launch_ranks(n, argv, timeout):
     s.close()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool supports dmabuf IPC only; with the legacy mode RCCL's
+        # (and torch's) cross-process buffer sharing fails in hipIpcGetMemHandle ("invalid argument").  The image exports
+        # it already; it is set here so that ranks spawned from a scrubbed environment still get it.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env))
     deadline = time.monotonic() + timeout
     rc = 0
     while procs:
@@ -250,7 +254,7 @@ def main():
                    "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
         "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
-        "roofline": None, "cpu_baseline": None, "f16x2_opt_in": None, "train": None, "faceformer": None, "flame": None,
+        "roofline": None, "cpu_baseline": None, "precision_modes": None, "train": None, "faceformer": None, "flame": None,
         "clip_text": None,
     }
     printed = threading.Lock()
@@ -287,11 +291,11 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
     ref_out = {k: out[k].clone() for k in ("predicted_exp", "predicted_jaw")}
-    side = pipe.side          # a second pipeline of this process keeps the high-priority stream the first one used
+    line["config"]["replay_streams"] = getattr(pipe, "stream_choice", None)
     del pipe, out
     torch.cuda.empty_cache()
-    if args.prec == "bf16x3" and not args.no_train and world == 1:      # N = 1 only, like the CPU baseline
-        run_leg("f16x2_opt_in", lambda: measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args, side))
+    if not args.no_train and world == 1:      # N = 1 only, like the CPU baseline
+        run_leg("precision_modes", lambda: measure_precision_modes(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args.prec, args))
         torch.cuda.empty_cache()
     if not args.no_train:
         run_leg("faceformer", lambda: measure_faceformer(dev))
@@ -413,7 +417,7 @@ def gemm_family(kw):
         from avi_talking_amd import ops
         kt = 64 if (kw.get("prec", 3) & 0xff) == 1 else 32
         M, N, K, batch = kw["M"], kw["N"], kw["K"], kw.get("batch", 1)
-        cus = ops.CU_BUDGET if 0 < ops.CU_BUDGET <= 256 else 256
+        cus = kw.get("cus", 0) if 0 < kw.get("cus", 0) <= 256 else 256
 
         def score(bm, bn, eff):                      # csrc/gemm.hip tile_score
             tiles = -(-M // bm) * -(-N // bn) * batch
@@ -744,38 +748,49 @@ def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16):
             "units": units}
 
 
-def measure_f16x2(wa, wh, wp, dev, pcm, voxel, noise, ref_out, args, side=None):
-    """Secondary, never the headline: the same config[1] pass in the OPT-IN fp16 mode (AVI_PREC_F16X2: fp16 hi/lo activation
-    planes x one fp16 weight plane on the plane-operand GEMMs, every sampler matrix one fp16 plane; the reference itself
-    runs fp16 autocast), with its own parity line: max-abs difference of its coefficients from the default 3-term pass on
-    the same inputs (the default is 2e-5 from the oracle; tests/test_gpu_emote.py pins this mode below north_star's 1e-3
-    against the oracle).  The parity line comes from a pipeline built here; the TIMING comes from a child process running
-    this script's own timed region with --prec f16x2 (a second pipeline captured in one process replays 10-30 % slower
-    than the same pipeline in a process of its own - measured 13.8-14.9 vs 11.0-11.1 ms, also over 300 steps - so an
-    in-process figure would not be what a user of the mode gets)."""
-    import subprocess
-    from avi_talking_amd import ops
+def measure_precision_modes(wa, wh, wp, dev, pcm, voxel, noise, ref_out, ref_name, args):
+    """Secondary: the same config[1] pass under the other precision plans (ops.PrecPlan), each with its own parity line:
+    max-abs difference of its coefficients from the bf16x3 (3-term) pass on the same inputs (that mode is 2e-5 from the
+    oracle; tests/test_gpu_mixed_prec.py and tests/test_gpu_emote.py pin every plan against the oracle itself).  Timed IN
+    THIS PROCESS with the headline's own timed region (pipelined two-graph replay, `--steps` passes after `--warmup`):
+    pipelines of one device share their streams (host/pipeline.device_streams), so a second pipeline object replays as
+    fast as the first (tests/test_gpu_fullsize.py::test_second_pipeline_replays_as_fast)."""
     from avi_talking_amd.host.pipeline import SamplingPipeline
-    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=ops.PREC_F16X2, joint_norm=args.joint_norm, side_stream=side)
-    o = pipe.run(pcm, voxel, noise)
-    torch.cuda.synchronize(dev)
-    err = max((o["predicted_exp"] - ref_out["predicted_exp"]).abs().max().item(),
-              (o["predicted_jaw"] - ref_out["predicted_jaw"]).abs().max().item())
-    del pipe, o
-    torch.cuda.empty_cache()
-    cmd = [sys.executable, os.path.abspath(__file__), "--prec", "f16x2", "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--no-cpu-baseline", "--no-train", "--no-roofline"] + (["--joint-norm"] if args.joint_norm else [])
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AVI_BENCH_FORCE_DIST")}
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        raise RuntimeError(f"child bench failed ({r.returncode}): {r.stderr[-200:]}")
-    child = json.loads(lines[0])
-    return {"workload": "configs[1] in the opt-in fp16 mode: 2 MFMA per product (fp16 hi/lo activation planes x one fp16 "
-                        "weight plane) on conv layers 1-6 and the encoder projections, every sampler matrix one fp16 plane",
-            "dtype": "f16x2", "ms_per_step": child["ms_per_step"], "frames_per_s": child["value"], "steps": child["steps"],
-            "timed_in": "child process: python bench.py --prec f16x2 (same timed region)",
-            "max_abs_coeff_diff_vs_default": float(f"{err:.3e}"), "gate": 1e-3}
+    out = {"reference_mode_for_diff": "bf16x3", "modes": []}
+    base = ref_out if ref_name == "bf16x3" else None
+    order = [m for m in ("bf16x3", "mixed", "mixed_ffn", "f16x2") if m != ref_name]
+    for mode in order:
+        pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=mode, joint_norm=args.joint_norm)
+        o = pipe.run(pcm, voxel, noise)
+        torch.cuda.synchronize(dev)
+        cur = {k: o[k].clone() for k in ("predicted_exp", "predicted_jaw")}
+        if mode == "bf16x3":
+            base = cur
+        pipe.capture_pipelined(pcm, voxel, noise)
+        for _ in range(args.warmup):
+            pipe.replay_pipelined()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.replay_pipelined()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        rec = {"dtype": mode, "plan": repr(pipe.plan), "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "frames_per_s": round(B_CLIPS * T_FRAMES * args.steps / dt, 1), "steps": args.steps,
+               "_out": cur}
+        out["modes"].append(rec)
+        del pipe, o
+        torch.cuda.empty_cache()
+    if base is None:
+        base = ref_out
+    for rec in out["modes"]:
+        cur = rec.pop("_out")
+        rec["max_abs_coeff_diff_vs_bf16x3"] = float("%.3e" % max((cur[k] - base[k]).abs().max().item() for k in cur))
+    if ref_name != "bf16x3":
+        out["headline_max_abs_coeff_diff_vs_bf16x3"] = float(
+            "%.3e" % max((ref_out[k] - base[k]).abs().max().item() for k in ref_out))
+    out["gates"] = {"north_star": 1e-3, "mixed (tests/test_gpu_mixed_prec.py, vs oracle)": 3e-4}
+    return out
 
 
 def measure_faceformer(dev, reps=5):

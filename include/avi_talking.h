@@ -145,7 +145,9 @@ int avi_group_pad_pack(const float* h, int B, int T, int G, int Cg, int pad, flo
 /* wav2vec2's positional conv embedding in one launch (HF Wav2Vec2PositionalConvEmbedding behind models/lib/wav2vec.py:142-148):
  * out[b][t][:] = x[b][t][:] + gelu(conv1d(x, k = taps, groups, padding = taps/2)[t] + bias), last extra frame dropped.
  * x, out [B][T][C] fp32 (C = groups * 48, taps = 128: wav2vec2-base); w_hi / w_lo: bf16 hi / lo planes
- * [groups][rows_per_group >= 48][taps * 48], W[g][n][tap * 48 + ch] = conv.weight[g * 48 + n][ch][tap] (weight norm folded). */
+ * [groups][rows_per_group >= 48][taps * 48], W[g][n][tap * 48 + ch] = conv.weight[g * 48 + n][ch][tap] (weight norm folded).
+ * NOT in place: `out` must not overlap `x` (a workgroup reads a +/-64-frame halo of x that its neighbours store as out);
+ * overlapping ranges return AVI_EINVAL. */
 int avi_posconv_gelu_residual(const float* x, int B, int T, int C, int groups, int taps, const uint16_t* w_hi,
                               const uint16_t* w_lo, int rows_per_group, const float* bias, float* out, void* stream);
 
@@ -458,8 +460,10 @@ int avi_soft_clip_loss(const float* proj, const float* target, int B, int D, flo
 /* Fused AdamW over one flat parameter region (torch.optim.AdamW semantics, train_diffusion_prior.py:997-1004),
  * n % 4 == 0, step >= 1; g is multiplied by grad_scale first (1/world for DP-averaged sums).
  * hi/lo (both or neither): also emit the bf16 hi/lo planes of the updated values for avi_gemm.
- * dyn (device pointer or NULL): {lr, 1-beta1^step, 1/sqrt(1-beta2^step)} override the scalar arguments, so a
- * captured hipGraph can be replayed with a new learning rate every step. */
+ * dyn (device pointer or NULL, 4 floats): {lr, 1-beta1^step, 1/sqrt(1-beta2^step), beta1 (0 = keep the argument)}
+ * override the scalar arguments, so a captured hipGraph can be replayed with a new learning rate AND a new beta1 every
+ * step: the reference's OneCycleLR has cycle_momentum on (train_diffusion_prior.py:351-357), which moves AdamW's beta1
+ * between 0.95 and 0.85; the first bias correction is formed from the step's own beta1, as torch does. */
 int avi_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, const float* dyn, uint16_t* hi, uint16_t* lo,
               void* stream);

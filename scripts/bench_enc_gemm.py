@@ -34,8 +34,7 @@ for name, N, K, act, resid in shapes:
     xp.hi.copy_(hi.view(torch.int16)); xp.lo.copy_((x - hi.float()).to(dt).view(torch.int16))
     pw = ops.PackedWeight(torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev))
     R = torch.randn(M, N, device=dev) if resid else None
-    ops.CU_BUDGET = cus
-    run = lambda: ops.linear_planes(xp, pw, act=act, residual=R, prec=prec, out_planes=not resid)
+    run = lambda: ops.linear_planes(xp, pw, act=act, residual=R, prec=prec, out_planes=not resid, cus=cus)
     for _ in range(3):
         run()
     torch.cuda.synchronize()

@@ -204,19 +204,14 @@ def test_bench_gpus_flag_spawns_ranks_dry_run():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["dry_run"] is True and rec["grad_spans_reduced_once"] is True
 
 
-def test_bench_launcher_reports_failing_rank():
+def test_bench_launcher_reports_failing_rank(tmp_path):
     """A rank that dies makes the launcher kill the rest and exit non-zero (never a silent success)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, os; sys.path.insert(0, %r); sys.argv=['bench.py']; import bench; "
-            "bench.__file__ = os.path.join(%r, 'tests', '_failing_rank.py'); "
-            "sys.exit(bench.launch_ranks(2, [], 60))" % (root, root))
-    helper = os.path.join(root, "tests", "_failing_rank.py")
-    with open(helper, "w") as fh:
-        fh.write("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(120)\n")
-    try:
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
-    finally:
-        os.remove(helper)
+    helper = tmp_path / "failing_rank.py"
+    helper.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(120)\n")
+    code = ("import sys; sys.path.insert(0, %r); sys.argv=['bench.py']; import bench; "
+            "sys.exit(bench.launch_ranks(2, [], 60, script=%r))" % (root, str(helper)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 7, (r.returncode, r.stderr[-1000:])

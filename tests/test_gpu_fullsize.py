@@ -125,3 +125,64 @@ def test_pipelined_replay_equals_plain_replay(gpu):
     torch.cuda.synchronize()
     assert torch.equal(out["predicted_exp"], exp) and torch.equal(out["predicted_jaw"], jaw)
     assert torch.equal(out["style_emb"], style)
+
+
+def test_replay_pipelined_takes_the_next_batch(gpu):
+    """replay_pipelined(pcm, voxel, noise) has replay()'s input-update contract: batches A, B, A handed over back to back
+    (no synchronisation in between) each return what a fresh eager pass on that batch returns, bit for bit."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu)
+    A = [t.to(gpu) for t in _inputs(32, 801)]
+    Bt = [t.to(gpu) for t in _inputs(32, 802)]
+    ref = []
+    for batch in (A, Bt):
+        o = pipe.run(*batch)
+        torch.cuda.synchronize()
+        ref.append({k: o[k].clone() for k in ("predicted_exp", "predicted_jaw", "style_emb")})
+    pipe.capture_pipelined(*A)
+    got = []
+    for batch in (A, Bt, A):
+        o = pipe.replay_pipelined(*batch)
+        pipe._s_head.synchronize()                   # the pass's own results (the next pass overwrites the static outputs)
+        got.append({k: o[k].clone() for k in ref[0]})
+    for g, r in zip(got, (ref[0], ref[1], ref[0])):
+        for k in r:
+            assert torch.equal(g[k], r[k]), k
+    with pytest.raises(ValueError):
+        pipe.replay_pipelined(pcm=A[0][:16])
+
+
+def test_second_pipeline_replays_as_fast(gpu):
+    """Two pipeline objects captured in ONE process (two precisions of the same batch) replay within 3 % of what each
+    does when it is the only pipeline the process has captured so far.  Round 2 measured the second object 10-30 % slower;
+    the cause was per-object streams (a new side stream and five new pool streams per object changed which hardware queue
+    the body, head and sampler of the second object were multiplexed onto): streams are now shared per device
+    (host/pipeline.device_streams)."""
+    import time
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline, device_streams
+    wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
+    pcm, voxel, noise = (t.to(gpu) for t in _inputs(32, 778))
+
+    def timed(pipe, n=30):
+        for _ in range(5):
+            pipe.replay_pipelined()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            pipe.replay_pipelined()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    first = SamplingPipeline(wa, wh, wp, device=gpu, prec="bf16x3").capture_pipelined(pcm, voxel, noise)
+    t_first = min(timed(first) for _ in range(2))
+    second = SamplingPipeline(wa, wh, wp, device=gpu, prec="bf16x3").capture_pipelined(pcm, voxel, noise)
+    t_second = min(timed(second) for _ in range(2))
+    t_first_again = min(timed(first) for _ in range(2))
+    st = device_streams(gpu)
+    assert second.side is first.side and second._s_body is first._s_body and second._s_head is first._s_head
+    assert first.stream_choice["head"] == second.stream_choice["head"] == st["pick"]
+    print(f"first {t_first:.3f} ms, second object {t_second:.3f} ms, first again {t_first_again:.3f} ms per pass; "
+          f"stream pick {st['pick']} of candidates {st['timings_ms']}")
+    assert t_second < 1.03 * t_first and t_first_again < 1.03 * t_first

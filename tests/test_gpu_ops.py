@@ -237,7 +237,7 @@ def test_linear_ln_skinny(gpu, M, N, K, do_ln, res):
                                           (4000, 512, 1536, 224), (333, 256, 192, 224)])
 def test_planes_gemm_tile_shapes(gpu, M, N, K, budget):
     """The plane-input GEMM picks its tile (256x256 / 128x192 / 128x256) from the fill of the CUs it may count on
-    (ops.CU_BUDGET -> AviGemm.cus); every choice must give the same result."""
+    (the ``cus`` argument -> AviGemm.cus); every choice must give the same result."""
     from avi_talking_amd import ops
     x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
     ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
@@ -246,12 +246,8 @@ def test_planes_gemm_tile_shapes(gpu, M, N, K, budget):
     hi = x.to(torch.bfloat16)
     xp.hi.copy_(hi.view(torch.int16).to(gpu))
     xp.lo.copy_((x - hi.float()).to(torch.bfloat16).view(torch.int16).to(gpu))
-    ops.CU_BUDGET = budget
-    try:
-        out = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu)).cpu().double()
-        outp = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu), out_planes=True)
-    finally:
-        ops.CU_BUDGET = 0
+    out = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu), cus=budget).cpu().double()
+    outp = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=r.to(gpu), out_planes=True, cus=budget)
     err = (out - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), err
     assert (outp.float().cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, (K / 64) ** 0.5) + 1e-4
@@ -279,7 +275,7 @@ def test_pingpong_gemm_cold_operands(gpu, M, N, K):
         assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), (rnd, err)
 
 
-@pytest.mark.parametrize("B,T", [(2, 250), (1, 100), (3, 129), (1, 7)])
+@pytest.mark.parametrize("B,T", [(2, 250), (1, 100), (3, 129), (1, 7), (3, 1), (3, 127), (3, 500)])
 def test_posconv_gelu_residual(gpu, B, T):
     """wav2vec2's positional conv embedding in one launch (csrc/posconv.hip) against torch's grouped Conv1d:
     x + gelu(conv1d(x, k=128, groups=16, padding=64)[..., :-1] + bias); frames at the clip's ends see the zero padding."""
@@ -295,9 +291,56 @@ def test_posconv_gelu_residual(gpu, B, T):
     wpad = torch.zeros((G, 64, K * cg))
     wpad[:, :cg] = wg
     pw = ops.PackedWeight(wpad.reshape(G * 64, K * cg).to(gpu))
-    out = ops.posconv_gelu_residual(x.to(gpu), pw, bias.to(gpu), G, K, 64).cpu().double()
+    xg_, bg_ = x.to(gpu), bias.to(gpu)
+    out = ops.posconv_gelu_residual(xg_, pw, bg_, G, K, 64).cpu().double()
     err = (out - ref).abs().max().item()
     assert err < 5e-5, err
+    # A/B against the older path (regrouping launch + overlapping-row GEMM per (clip, group), AVI_W2V_POSCONV=gemm)
+    xg = ops.group_pad_pack(xg_, G, K // 2)
+    h = torch.empty_like(xg_)
+    Tp = T + K
+    ops.gemm_raw(A=xg.data_ptr(), lda=cg, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=h.data_ptr(), ldc=Cc, M=T, N=cg,
+                 K=K * cg, bias=bg_.data_ptr(), R=xg_.data_ptr(), ldr=Cc, act=ops.ACT_GELU, prec=ops.PREC_BF16X3,
+                 batch=B * G, z_inner=G, sA=(G * Tp * cg, Tp * cg), sW=(0, 64 * K * cg), sC=(T * Cc, cg), sB=(0, cg),
+                 sR=(T * Cc, cg))
+    assert (h.cpu().double() - out).abs().max().item() < 5e-5
+
+
+def test_posconv_rejects_in_place_and_overlap(gpu):
+    """The kernel reads a +/-64-frame halo of x that neighbouring workgroups store as out: aliasing is refused at the ABI."""
+    from avi_talking_amd import lib as L, ops
+    G, K, Cc, B, T = 16, 128, 768, 2, 200
+    pw = ops.PackedWeight(torch.zeros((G * 64, K * (Cc // G)), device=gpu))
+    bias = torch.zeros(Cc, device=gpu)
+    buf = torch.zeros((2 * B * T * Cc,), device=gpu)
+    x = buf[: B * T * Cc]
+    call = lambda out_ptr: L.load().avi_posconv_gelu_residual(x.data_ptr(), B, T, Cc, G, K, pw.hi.data_ptr(), pw.lo.data_ptr(),
+                                                              64, bias.data_ptr(), out_ptr, L.stream_ptr())
+    assert call(x.data_ptr()) == L.AVI_EINVAL                               # in place
+    assert call(x.data_ptr() + 4 * (B * T * Cc - Cc)) == L.AVI_EINVAL       # tail of x overlaps the head of out
+    assert call(x.data_ptr() + 4 * B * T * Cc) == 0                          # adjacent, disjoint: fine
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
+def test_audio_normalize_unaligned_view(gpu, dtype):
+    """A pcm pointer taken from an offset view (not 16-byte aligned) takes the scalar loads: same result as the aligned copy."""
+    from avi_talking_amd import lib as L
+    B, N = 2, 4096
+    g = torch.Generator().manual_seed(17)
+    base = (torch.randn(B * N + 8, generator=g) * 3000).to(dtype).to(gpu)
+    view = base[1: 1 + B * N]                        # 2 or 4 bytes past a 16-byte boundary
+    assert view.data_ptr() % 16 != 0
+    outs = []
+    for src in (view, view.clone()):
+        out = torch.empty((B, N), dtype=torch.float32, device=gpu)
+        stats = torch.empty((2 * B,), dtype=torch.float64, device=gpu)
+        L.check(L.load().avi_audio_normalize(src.data_ptr(), int(dtype == torch.int16), B, N, 0, 1e-7, out.data_ptr(),
+                                             stats.data_ptr(), L.stream_ptr()), "avi_audio_normalize")
+        outs.append(out.cpu())
+    x = view.cpu().float().view(B, N)
+    ref = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-7)
+    assert (outs[0] - ref).abs().max().item() < 1e-5 and (outs[0] - outs[1]).abs().max().item() < 1e-6
 
 
 def test_transpose_jobs_and_table(gpu):

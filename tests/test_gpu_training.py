@@ -81,6 +81,42 @@ def test_adamw_kernel_matches_torch(gpu):
         assert (recon.cpu() - dp.cpu()).abs().max().item() < 2e-5 * dp.abs().max().item()
 
 
+def test_adamw_follows_one_cycle_lr_and_momentum(gpu):
+    """The reference's scheduler (train_diffusion_prior.py:351-357) has torch's default cycle_momentum=True: every step
+    changes the rate AND AdamW's beta1.  avi_adamw reading {lr, bias corrections, beta1} from the `dyn` device buffer
+    (what a replayed hipGraph sees) against torch.optim.AdamW driven by torch's own OneCycleLR, 12 steps."""
+    import math
+    import avi_talking_amd.lib as L
+    from avi_talking_amd.host.schedule import reference_schedule
+    n, epochs, per_epoch = 4096 * 5, 3, 1
+    g0 = torch.Generator().manual_seed(7)
+    p = torch.randn(n, generator=g0)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=1e-2)
+    total = epochs * per_epoch * 5
+    tsched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=total, final_div_factor=1000,
+                                                 pct_start=2 / epochs)
+    mine = reference_schedule(1e-3, epochs, per_epoch)
+    dp, m, v = p.to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    dyn = torch.zeros(4, device=gpu)
+    for step in range(1, total):
+        grad = torch.randn(n, generator=g0)
+        ref.grad = grad.clone()
+        opt.step()
+        lr, b1 = mine.lr_at(step - 1), mine.momentum_at(step - 1)
+        assert abs(b1 - opt.param_groups[0]["betas"][0]) < 1e-12
+        dyn.copy_(torch.tensor([lr, 1 - b1 ** step, 1 / math.sqrt(1 - 0.999 ** step), b1]))
+        # scalar arguments deliberately stale (the graph's captured values): dyn overrides them
+        L.check(L.load().avi_adamw(dp.data_ptr(), grad.to(gpu).data_ptr(), m.data_ptr(), v.data_ptr(), n, 123.0, 0.9, 0.999,
+                                   1e-8, 1e-2, 1, 1.0, dyn.data_ptr(), None, None, L.stream_ptr()), "adamw")
+        tsched.step()
+    err = (dp.cpu() - ref.detach()).abs().max().item()
+    print(f"AdamW under OneCycleLR with cycled beta1, {total - 1} steps: max-abs parameter difference {err:.2e}")
+    assert err < 5e-6
+    # and with beta1 held at 0.9 the result differs: the cycle is not a no-op
+    assert abs(mine.momentum_at(0) - 0.95) < 1e-12 and abs(mine.momentum_at(int(mine.up_end)) - 0.85) < 1e-2
+
+
 def test_train_step_updates_parameters(gpu, setup):
     from avi_talking_amd.host.training import PriorTrainer, no_decay
     voxel, target, times, noise, bk, ik, masks = setup["inputs"]

@@ -99,6 +99,9 @@ def test_one_cycle_lr_matches_torch(epochs, n):
     for s in range(total - 1):
         assert abs(opt.param_groups[0]["lr"] - mine.lr_at(s)) <= 1e-12 + 1e-9 * mine.lr_at(s)
         assert abs(mine.get_last_lr()[0] - mine.lr_at(s)) == 0
+        # cycle_momentum (torch's default): AdamW's beta1 runs inversely to the rate, beta2 stays
+        assert abs(opt.param_groups[0]["betas"][0] - mine.momentum_at(s)) <= 1e-12
+        assert opt.param_groups[0]["betas"][1] == 0.999
         opt.step()
         ref.step()
         mine.step()
