@@ -47,8 +47,15 @@ def device_streams(device):
 
 
 class SamplingPipeline:
-    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None):
+    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None,
+                 rng_seed=None):
+        """``rng_seed``: draw the DDPM noise INSIDE the pass from the library's device-resident Philox stream (host/rng.py)
+        whenever a call passes ``noise=None`` - the reference draws it inside its loop (models/diffusion_prior.py:337,
+        349-351); a captured pass then draws fresh noise at every replay.  None = the caller supplies the noise tensor."""
         self.device = torch.device(device)
+        from .rng import DeviceRng
+        self.rng = None if rng_seed is None else DeviceRng(rng_seed, self.device)
+        self._noise_buf = None
         self.plan = plan = ops.prec_plan(prec)       # AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=plan, joint_norm=joint_norm)
         # the uniform fp16 mode also stores the sampler's attention matrices as one fp16 plane (the mixed plans leave the
@@ -87,6 +94,8 @@ class SamplingPipeline:
         # 2. fork: the sampler (32 workgroups for ~12 ms) on the side stream, the audio encoder on this one
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
+            if noise is None:            # the draws of the reference's loop (:337,349-351), inside the pass
+                noise = self._draw_noise(B)
             if aligner_on_side:
                 clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
             style = self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
@@ -102,17 +111,30 @@ class SamplingPipeline:
         cur.wait_stream(self.side)
         return sample["audio_feature"], style
 
-    def run(self, pcm, voxel, noise):
-        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128)
-        -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
+    def _draw_noise(self, B):
+        """(T_d+1, B, 1, 128) standard normals from the device stream into a buffer this object keeps, then the offset moves
+        on (both launches on the current stream: inside a capture they are nodes of the graph)."""
+        from . import rng as R
+        if self.rng is None:
+            raise ValueError("noise=None needs a pipeline built with rng_seed=... (in-pass draws)")
+        T = self.prior.noise_scheduler.num_timesteps
+        if self._noise_buf is None or self._noise_buf.shape[1] != B:
+            self._noise_buf = torch.empty((T + 1, B, 1, 128), dtype=torch.float32, device=self.device)
+        self.rng.fill(self._noise_buf, R.NORMAL, subsequence=0)
+        self.rng.advance(1)
+        return self._noise_buf
+
+    def run(self, pcm, voxel, noise=None):
+        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside
+        the pass, ``rng_seed``) -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
         feat, style = self._body(pcm, voxel, noise)
         out = self.talking_head.head(feat, style)
         out["style_emb"] = style
         return out
 
     # ---- hipGraph capture of the whole pass (static input buffers, replayed per batch)
-    def capture(self, pcm, voxel, noise, warmup=2):
-        self._static = (pcm.clone(), voxel.clone(), noise.clone())
+    def capture(self, pcm, voxel, noise=None, warmup=2):
+        self._static = (pcm.clone(), voxel.clone(), None if noise is None else noise.clone())
         for _ in range(warmup):
             self.run(*self._static)
         torch.cuda.synchronize(self.device)
@@ -126,12 +148,14 @@ class SamplingPipeline:
             raise RuntimeError("capture() first")
         for dst, src in zip(self._static, (pcm, voxel, noise)):
             if src is not None:
+                if dst is None:
+                    raise ValueError("the pass was captured with in-pass noise draws: it takes no noise tensor")
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
         return self._out
 
     # ---- software-pipelined replay: the serial end of a pass runs beside its successor
-    def capture_pipelined(self, pcm, voxel, noise, warmup=2):
+    def capture_pipelined(self, pcm, voxel, noise=None, warmup=2):
         """Two graphs instead of one.  A pass ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip
         almost idle) and begins with the aligner (0.19 ms of split-K launches that depend on the text feature alone).
         Captured as `body` and `head` and replayed on two streams, the head of pass k runs beside the start of pass k+1;
@@ -144,7 +168,7 @@ class SamplingPipeline:
         few in-order hardware queues, the aligner's stream shared the body's, and its launches ran BETWEEN two bodies
         (0.19 ms per pass on the critical path, scripts/pass_timeline.py --gap)."""
         from .. import lib as L
-        self._static = (pcm.clone(), voxel.clone(), noise.clone())
+        self._static = (pcm.clone(), voxel.clone(), None if noise is None else noise.clone())
         for _ in range(warmup):
             self.run(*self._static)
         torch.cuda.synchronize(self.device)
@@ -207,6 +231,8 @@ class SamplingPipeline:
         with torch.cuda.stream(self._s_body):
             for dst, src in zip(self._static, (pcm, voxel, noise)):
                 if src is not None:
+                    if dst is None:
+                        raise ValueError("the pass was captured with in-pass noise draws: it takes no noise tensor")
                     if src.shape != dst.shape or src.dtype != dst.dtype:
                         raise ValueError(f"replay_pipelined: input {tuple(src.shape)} {src.dtype} does not match the "
                                          f"captured {tuple(dst.shape)} {dst.dtype}")

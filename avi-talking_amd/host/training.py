@@ -577,6 +577,22 @@ class PriorTrainer:
                     brain_keep=(r(B) < 0.8).to(torch.uint8), image_keep=(r(B) < 0.8).to(torch.uint8),
                     dropout_masks=masks)
 
+    def draw_device(self, rng, rand):
+        """The same draws from the library's device-resident Philox stream (host/rng.py), written INTO the tensors of
+        ``rand`` (a dict shaped like ``draw``'s) by launches on the current stream, then the stream's offset moves on: inside
+        a captured step these are nodes of the graph, so every replay trains on fresh times / noise / masks, as the
+        reference's step does (train_diffusion_prior.py:449 -> models/diffusion_prior.py:445,453,255-259; Dropout 0.5 /
+        0.15 of BrainNetwork :62-75).  One subsequence per tensor."""
+        from . import rng as R
+        rng.fill(rand["times"], R.RANDINT_I32, 0, 100.0)
+        rng.fill(rand["noise"], R.NORMAL, 1)
+        rng.fill(rand["brain_keep"], R.BERNOULLI_U8, 2, 0.8)
+        rng.fill(rand["image_keep"], R.BERNOULLI_U8, 3, 0.8)
+        for i, m in enumerate(rand["dropout_masks"]):
+            rng.fill(m, R.KEEP_SCALED, 4 + i, 0.5 if i == 0 else 0.15)
+        rng.advance(1)
+        return rand
+
     # ------------------------------------------------------------------ forward + backward
     def forward_backward(self, voxel, clip_target, times, noise, temp, brain_keep=None, image_keep=None,
                          dropout_masks=None):
@@ -784,8 +800,14 @@ class PriorTrainer:
         return out
 
     # ------------------------------------------------------------------ hipGraph capture (single GPU)
-    def capture_step(self, voxel, clip_target, temp, rand, warmup=2):
-        """Capture forward + backward + AdamW (no collective) into one hipGraph over static input buffers."""
+    def capture_step(self, voxel, clip_target, temp, rand=None, warmup=2, rng=None):
+        """Capture forward + backward + AdamW (no collective) into one hipGraph over static input buffers.  ``rng`` (a
+        host/rng.DeviceRng): the step's random inputs are drawn INSIDE the graph (fresh at every replay); otherwise the
+        tensors of ``rand`` are frozen into it (parity runs)."""
+        if rand is None:
+            if rng is None:
+                raise ValueError("capture_step needs rand (recorded draws) or rng (in-graph draws)")
+            rand = self.draw(voxel.shape[0])                  # shapes and dtypes of the static buffers
         self._static = dict(voxel=voxel.clone(), target=clip_target.clone(),
                             rand={k: ([m.clone() for m in v] if isinstance(v, list) else v.clone())
                                   for k, v in rand.items()})
@@ -793,6 +815,8 @@ class PriorTrainer:
 
         def body(in_graph):
             r = st["rand"]
+            if rng is not None:
+                self.draw_device(rng, r)
             out = self.forward_backward(st["voxel"], st["target"], r["times"], r["noise"], temp, r["brain_keep"],
                                         r["image_keep"], r["dropout_masks"])
             if self.allreduce_grads() != 1:

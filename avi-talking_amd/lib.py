@@ -148,6 +148,8 @@ SIGNATURES = {
     "avi_prior_time_table": [_vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_faceformer_decode_chunked": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "avi_rng_fill": [_vp, C.c_uint, _i, _f, _ll, _vp, _vp],
+    "avi_rng_advance": [_vp, C.c_ulonglong, _vp],
     "avi_faceformer_tf_embed": [_vp, _vp, _i, _i, _vp, _vp],
     "avi_faceformer_steps_work_floats": [_i, _i, C.POINTER(_ll)],
     "avi_faceformer_decode_steps": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -197,7 +197,10 @@ def main():
 
     prec = ops.prec_plan(args.prec)
     wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
-    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=prec, joint_norm=args.joint_norm)
+    # the DDPM noise of every timed pass is drawn INSIDE the pass (graph nodes, device-resident Philox stream), as the
+    # reference draws it inside its loop (models/diffusion_prior.py:337,349-351); `noise` below is the recorded tensor the
+    # parity and per-kernel legs inject
+    pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=prec, joint_norm=args.joint_norm, rng_seed=4242 + rank)
     pcm = synth_audio(B_CLIPS, N_SAMPLES, 1234 + rank).to(dev)
     voxel = torch.randn(B_CLIPS, 768, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
     noise = torch.randn(101, B_CLIPS, 1, 128, generator=torch.Generator().manual_seed(rank)).to(dev)
@@ -207,14 +210,14 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     if args.no_graph:
-        step = lambda: pipe.run(pcm, voxel, noise)
+        step = lambda: pipe.run(pcm, voxel, None)
         for _ in range(2):
             step()
     elif args.no_pipeline:
-        pipe.capture(pcm, voxel, noise)
+        pipe.capture(pcm, voxel, None)
         step = lambda: pipe.replay()
     else:
-        pipe.capture_pipelined(pcm, voxel, noise)
+        pipe.capture_pipelined(pcm, voxel, None)
         step = lambda: pipe.replay_pipelined()
     for _ in range(args.warmup):
         step()
@@ -247,6 +250,8 @@ def main():
                    "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
                    "audio_normalisation": "joint over the batch" if args.joint_norm else "per clip",
                    "hipgraph": not args.no_graph,
+                   "random_draws": "in the pass: (101,B,1,128) DDPM noise from the library's Philox-4x32-10 stream, drawn by "
+                                   "nodes of the captured graph (fresh at every replay)",
                    "replay": "eager" if args.no_graph else "one graph per pass" if args.no_pipeline else
                              "two graphs per pass (body, head) on two streams: the head of pass k runs beside the start of pass "
                              "k+1, the aligner opens the sampler's branch beside the audio front end; every pass does all of its "
@@ -290,7 +295,10 @@ def main():
         run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, line["ms_per_step"]))
     if world == 1 and not args.no_cpu_baseline:
         run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
-    ref_out = {k: out[k].clone() for k in ("predicted_exp", "predicted_jaw")}
+    o_ref = pipe.run(pcm, voxel, noise)                      # recorded noise: the reference point of the parity diffs
+    torch.cuda.synchronize(dev)
+    ref_out = {k: o_ref[k].clone() for k in ("predicted_exp", "predicted_jaw")}
+    del o_ref
     line["config"]["replay_streams"] = getattr(pipe, "stream_choice", None)
     del pipe, out
     torch.cuda.empty_cache()
@@ -378,7 +386,9 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
     temp = 0.005
     graph = world == 1 and dist is None and not args.no_graph      # collectives stay outside a captured step
     if graph:
-        tr.capture_step(voxel, target, temp, rand)
+        # times / noise / cond-drop masks / dropout masks are drawn inside the captured step (train_diffusion_prior.py:449)
+        from avi_talking_amd.host.rng import DeviceRng
+        tr.capture_step(voxel, target, temp, rng=DeviceRng(4321 + rank, dev))
         step = tr.replay_step
     else:
         step = lambda: tr.train_step(voxel, target, temp, rand=rand)
@@ -408,6 +418,8 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
             "samples_per_s": round(world * B * args.train_steps / dt, 1), "ms_per_step": round(dt / args.train_steps * 1e3, 3),
             "steps": args.train_steps, "global_batch": world * B, "params_m": round(tr.store.numel / 1e6, 1),
             "allreduce_mb": round(tr.store.numel * 4 / 1e6, 1) if world > 1 else 0, "hipgraph": graph,
+            "random_draws": "inside the captured step (Philox stream: times, noise, cond-drop and dropout masks)" if graph
+                            else "recorded tensors",
             "dtype": "bf16x3", "loss_prior": round(lp, 5), "loss_nce": round(ln, 5)}
 
 
@@ -760,13 +772,13 @@ def measure_precision_modes(wa, wh, wp, dev, pcm, voxel, noise, ref_out, ref_nam
     base = ref_out if ref_name == "bf16x3" else None
     order = [m for m in ("bf16x3", "mixed", "mixed_ffn", "f16x2") if m != ref_name]
     for mode in order:
-        pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=mode, joint_norm=args.joint_norm)
-        o = pipe.run(pcm, voxel, noise)
+        pipe = SamplingPipeline(wa, wh, wp, device=dev, prec=mode, joint_norm=args.joint_norm, rng_seed=777)
+        o = pipe.run(pcm, voxel, noise)                      # recorded noise for the diff, in-pass draws for the timing
         torch.cuda.synchronize(dev)
         cur = {k: o[k].clone() for k in ("predicted_exp", "predicted_jaw")}
         if mode == "bf16x3":
             base = cur
-        pipe.capture_pipelined(pcm, voxel, noise)
+        pipe.capture_pipelined(pcm, voxel, None)
         for _ in range(args.warmup):
             pipe.replay_pipelined()
         torch.cuda.synchronize(dev)

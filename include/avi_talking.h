@@ -469,6 +469,28 @@ int avi_adamw(float* p, const float* g, float* m, float* v, long long n, float l
               void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Random draws INSIDE the captured passes.  Replaces the torch-generator calls of the reference's steps:
+ * torch.randn(..., generator) for x_T and per DDPM step (models/diffusion_prior.py:337,349-351); timesteps, q_sample
+ * noise, prob_mask_like cond-drop masks and nn.Dropout masks of one training step (models/diffusion_prior.py:445,453,
+ * 255-259,62-75 via train_diffusion_prior.py:449).
+ * Generator: Philox-4x32-10; state = device uint64[2] {seed, offset}.  Element i of a fill is word (i & 3) of the block
+ * with counter (i >> 2 [48 bits] | subsequence << 48, offset) under key seed: fills with different `subsequence`
+ * (< 65536) or different offsets never overlap.  avi_rng_advance adds `delta` to the offset (the last node of a captured
+ * pass: every replay then draws fresh numbers; a replayed sequence is reproduced by resetting the state).
+ * kinds: RAW uint32 words | NORMAL fp32 (Box-Muller on word pairs) | KEEP_SCALED fp32 (u >= param ? 1/(1-param) : 0, a
+ * dropout keep mask with drop probability param) | BERNOULLI_U8 (u < param) | RANDINT_I32 (floor(word * param / 2^32),
+ * param = exclusive upper bound <= 2^24) | UNIFORM fp32 in [0,1) (24 bits).  `out` aligned to 4 elements. */
+#define AVI_RNG_RAW 0
+#define AVI_RNG_NORMAL 1
+#define AVI_RNG_KEEP_SCALED 2
+#define AVI_RNG_BERNOULLI_U8 3
+#define AVI_RNG_RANDINT_I32 4
+#define AVI_RNG_UNIFORM 5
+int avi_rng_fill(const unsigned long long* state, unsigned subsequence, int kind, float param, long long n, void* out,
+                 void* stream);
+int avi_rng_advance(unsigned long long* state, unsigned long long delta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * FLAME vertices.  Replaces `FLAME.forward(shape_params, expression_params, pose_params,
  * eye_pose_params)[0]` (third_party/inferno/inferno/models/DecaFLAME.py:222-244) = `lbs` of
  * third_party/inferno/inferno/utils/lbs.py:142-235 on the 5-joint head model (parents [-1,0,1,1,1]); landmarks are

@@ -240,3 +240,32 @@ def test_clip_text_oracle_matches_transformers_live():
         ref = m(input_ids=ids).last_hidden_state
     out = OC.clip_text_forward(sd, ids, layers=2, heads=4)
     assert (out - ref).abs().max().item() < 2e-5
+
+
+def test_philox_known_answer_vectors():
+    """oracle/rng.py philox4x32_10 against the known-answer vectors shipped with the Random123 library (kat_vectors:
+    philox4x32 10 rounds: zero counter and key; all-ones; the digits of pi)."""
+    from oracle import rng as OR
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = OR.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+        assert tuple(int(x) for x in got) == want
+
+
+def test_rng_oracle_streams():
+    """Addressing and transforms of oracle/rng.py: a fill is a prefix of a longer fill, subsequences / offsets / seeds give
+    different words, normals have unit moments, masks their keep rate."""
+    from oracle import rng as OR
+    a, b = OR.fill(5, 2, 1, OR.KIND_RAW, 10), OR.fill(5, 2, 1, OR.KIND_RAW, 1000)
+    assert np.array_equal(a, b[:10])
+    for other in (OR.fill(5, 2, 2, OR.KIND_RAW, 1000), OR.fill(5, 3, 1, OR.KIND_RAW, 1000), OR.fill(6, 2, 1, OR.KIND_RAW, 1000)):
+        assert (other == b).mean() < 0.01
+    z = OR.fill(5, 2, 1, OR.KIND_NORMAL, 200001)
+    assert z.dtype == np.float32 and abs(z.mean()) < 0.01 and abs(z.var() - 1) < 0.01
+    k = OR.fill(5, 2, 1, OR.KIND_KEEP_SCALED, 100000, 0.5)
+    assert set(np.unique(k)) == {0.0, 2.0} and abs((k > 0).mean() - 0.5) < 0.01
+    t = OR.fill(5, 2, 1, OR.KIND_RANDINT_I32, 100000, 100.0)
+    assert t.min() == 0 and t.max() == 99
