@@ -82,7 +82,8 @@ __device__ void add_layernorm(float* x, const float* r, long long rstride_unused
 
 __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceformerWeights w,
                                                                 const float* __restrict__ cross, int B, int T, int chunk,
-                                                                float* __restrict__ kv, float* __restrict__ out) {
+                                                                float* __restrict__ kv, float* __restrict__ out,
+                                                                uint16_t* __restrict__ out16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = w.D, V = w.V, dh = D / NH;
     float* x = sm;              // [D]   decoder stream
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(NT) void faceformer_decode_kernel(const AviFaceform
         if (tid < V) {
             float v = o[tid];
             if (w.coeff_std) v = v * w.coeff_std[tid] + w.coeff_mean[tid];   // un-normalise (:729)
-            out[((long long)b * T + i) * V + tid] = v;
+            if (out16) out16[((long long)b * T + i) * V + tid] = __builtin_bit_cast(uint16_t, (_Float16)v);
+            else out[((long long)b * T + i) * V + tid] = v;
         }
         matvec(w.wm, w.bm, o, V, D, emb, false, part);             // vertice_map feedback (on the NORMALISED frame)
     }
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(NT) void faceformer_tf_embed_kernel(const float* __
 
 }  // namespace
 
-extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
-                                             float* kv_scratch, float* out, void* stream) {
-    if (!w || !cross || !kv_scratch || !out || B <= 0 || T <= 0) return AVI_EINVAL;
+static int decode_chunked_impl(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                               float* kv_scratch, float* out, uint16_t* out16, void* stream) {
+    if (!w || !cross || !kv_scratch || (!out && !out16) || B <= 0 || T <= 0) return AVI_EINVAL;
     const int dh = w->D / NH;
     if (w->D < 16 || dh * NH != w->D || dh < 4 || (dh & (dh - 1)) != 0) return AVI_EINVAL;
     if (w->V < 1 || w->V > 64 || w->period < 1) return AVI_EINVAL;
@@ -224,8 +226,17 @@ extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, cons
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(faceformer_decode_kernel), 160 * 1024);
     hipLaunchKernelGGL(faceformer_decode_kernel, dim3(B), dim3(NT), smem, static_cast<hipStream_t>(stream), *w, cross,
-                       B, T, chunk, kv_scratch, out);
+                       B, T, chunk, kv_scratch, out, out16);
     return avi_launch_status();
+}
+
+extern "C" int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                                             float* kv_scratch, float* out, void* stream) {
+    return decode_chunked_impl(w, cross, B, T, chunk, kv_scratch, out, nullptr, stream);
+}
+extern "C" int avi_faceformer_decode_chunked_f16(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                                                 float* kv_scratch, uint16_t* out16, void* stream) {
+    return decode_chunked_impl(w, cross, B, T, chunk, kv_scratch, nullptr, out16, stream);
 }
 
 extern "C" int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int B, int T, float* kv_scratch,

@@ -30,6 +30,7 @@ struct Chain {
     const float* cross;
     float* kv;
     float* out;
+    uint16_t* out16;      // IEEE half output instead of `out` (long-form: half the coefficient bytes), or NULL
     float *o, *part, *att, *s1, *x2, *h, *s3, *st1, *st3;
     int B, T, D, chunk;
 };
@@ -397,7 +398,9 @@ __global__ __launch_bounds__(NT) void ff_lin_kernel(const Chain c, const int i) 
                 y[j] = v;       // normalised frame: what vertice_map feeds back (models/faceformer.py:722-725)
                 if (real && row) {
                     if (c.w.coeff_std) v = v * c.w.coeff_std[n] + c.w.coeff_mean[n];       // :729
-                    c.out[((long long)m * c.T + i) * c.w.V + n] = v;
+                    const long long oi = ((long long)m * c.T + i) * c.w.V + n;
+                    if (c.out16) c.out16[oi] = __builtin_bit_cast(uint16_t, (_Float16)v);
+                    else c.out[oi] = v;
                 }
             }
             if (row) *reinterpret_cast<f32x4*>(c.o + m * VP + n0) = y;
@@ -447,10 +450,10 @@ static void launch_lin(const Chain& c, int i, int tiles, hipStream_t s) {
     }
 }
 
-extern "C" int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
-                                           int B, int T, int chunk, float* kv_scratch, float* work, float* out,
-                                           void* stream) {
-    if (!w || !p || !cross || !kv_scratch || !work || !out || B <= 0 || B > MAXB || T <= 0) return AVI_EINVAL;
+static int decode_steps_impl(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
+                             int B, int T, int chunk, float* kv_scratch, float* work, float* out, uint16_t* out16,
+                             void* stream) {
+    if (!w || !p || !cross || !kv_scratch || !work || (!out && !out16) || B <= 0 || B > MAXB || T <= 0) return AVI_EINVAL;
     const int D = w->D, dh = D / NH;
     if (D % 64 || D > 1024 || (dh != 16 && dh != 32 && dh != 64 && dh != 128 && dh != 256)) return AVI_EINVAL;
     if (w->V < 1 || w->V > VP || w->period < 1) return AVI_EINVAL;
@@ -467,6 +470,7 @@ extern "C" int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const 
     c.cross = cross;
     c.kv = kv_scratch;
     c.out = out;
+    c.out16 = out16;
     c.B = B, c.T = T, c.D = D, c.chunk = chunk;
     float* q = work;
     c.o = q, q += (long long)B * VP;
@@ -495,4 +499,15 @@ extern "C" int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const 
         launch_lin<EPI_MAPR>(c, i, VP / 16, s);
     }
     return avi_launch_status();
+}
+
+extern "C" int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
+                                           int B, int T, int chunk, float* kv_scratch, float* work, float* out,
+                                           void* stream) {
+    return decode_steps_impl(w, p, cross, B, T, chunk, kv_scratch, work, out, nullptr, stream);
+}
+extern "C" int avi_faceformer_decode_steps_f16(const AviFaceformerWeights* w, const AviFaceformerPlanes* p,
+                                               const float* cross, int B, int T, int chunk, float* kv_scratch, float* work,
+                                               uint16_t* out16, void* stream) {
+    return decode_steps_impl(w, p, cross, B, T, chunk, kv_scratch, work, nullptr, out16, stream);
 }

@@ -176,10 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
     }
 
     // ---- epilogue: lane holds C[m = m0 + wm*WROWS + b*16 + fr][n = n0 + wn*BN/2 + a*16 + fq*4 + 0..3]
-    float* __restrict__ C = g.C + zo * g.sCo + zi * g.sCi;
+    float* __restrict__ C = g.C ? g.C + zo * g.sCo + zi * g.sCi : nullptr;
+    uint16_t* __restrict__ C16 = g.C16 ? g.C16 + zo * g.sCo + zi * g.sCi : nullptr;   // IEEE half copy of the result
     const float* __restrict__ bias = g.bias ? g.bias + zo * g.sBo + zi * g.sBi : nullptr;
     const float* __restrict__ R = g.R ? g.R + zo * g.sRo + zi * g.sRi : nullptr;
-    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+    const bool vec_ok = C && !C16 && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!R || (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = avi_act(acc[a][b][j] + bv[j], g.act) * sc[j] + sh[j];
-            float* cp = C + (long long)m * g.ldc + n;
+            const long long co = (long long)m * g.ldc + n;
+            float* cp = C + co;
             if (vec_ok && n + 3 < g.N) {
                 if (R) {
                     const float4 rv = *reinterpret_cast<const float4*>(R + (long long)m * g.ldr + n);
@@ -209,7 +211,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const AviGemm g, const int
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (n + j < g.N) cp[j] = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
+                    if (n + j < g.N) {
+                        const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
+                        if (C) cp[j] = y;
+                        if (C16) C16[co + j] = __builtin_bit_cast(uint16_t, (_Float16)y);
+                    }
             }
         }
     }
@@ -289,7 +295,7 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     if (!gp) return AVI_EINVAL;
     const AviGemm& g = *gp;
     const bool planes = g.Ahi != nullptr;
-    if ((!g.A && !planes) || !g.Whi || (!g.C && !g.Chi) || g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0)
+    if ((!g.A && !planes) || !g.Whi || (!g.C && !g.Chi && !g.C16) || g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0)
         return AVI_EINVAL;
     if (g.ldw && (g.ldw < g.K || (g.ldw & 7))) return AVI_EINVAL;
     if (g.batch < 1 || g.z_inner < 1 || (g.batch % g.z_inner) != 0 || g.batch > 65535) return AVI_EINVAL;
@@ -297,6 +303,7 @@ extern "C" int avi_gemm(const AviGemm* gp, void* stream) {
     if (g.Chi && ((g.ldc & 3) || (g.sCo & 3) || (g.sCi & 3) || (reinterpret_cast<uintptr_t>(g.Chi) & 7) ||
                   (reinterpret_cast<uintptr_t>(g.Clo) & 7)))
         return AVI_EINVAL;
+    if (g.C16 && (planes || (reinterpret_cast<uintptr_t>(g.C16) & 1))) return AVI_EINVAL;   // fp32-operand kernel only
     if (planes) {
         if ((g.lda & 7) || (g.sAo & 7) || (g.sAi & 7) || (reinterpret_cast<uintptr_t>(g.Ahi) & 15)) return AVI_EINVAL;
         if ((g.prec & 0xff) != AVI_PREC_BF16 && (!g.Alo || (reinterpret_cast<uintptr_t>(g.Alo) & 15))) return AVI_EINVAL;

@@ -170,9 +170,12 @@ class Faceformer:
             raise ValueError("chunk must be a positive multiple of the PPE period")
         return min(chunk, T)
 
-    def decode(self, hidden_states, chunk=None):
+    def decode(self, hidden_states, chunk=None, out_dtype=torch.float32):
         """The autoregressive loop of ``predict`` (:710-729) for memory ``hidden_states`` (B,T,D).  ``chunk``: attention
-        window for long-form decoding (None = the reference's full causal window, T <= 600)."""
+        window for long-form decoding (None = the reference's full causal window, T <= 600).  ``out_dtype`` float16: the
+        frame-writing kernel stores IEEE half (BASELINE.json configs[4] "fp16 coeffs"; the fed-back frame stays fp32)."""
+        if out_dtype not in (torch.float32, torch.float16):
+            raise ValueError("out_dtype must be float32 or float16")
         hs = hidden_states.to(self.device, torch.float32).contiguous()
         B, T, D = hs.shape
         if D != self.D:
@@ -180,21 +183,23 @@ class Faceformer:
         chunk = self._chunk(T, chunk)
         cross = ops.linear(ops.linear(hs, self.cross_v, prec=self.prec), self.cross_o, prec=self.prec)
         if self.use_steps:
-            return self._decode_steps(cross, B, T, chunk)
+            return self._decode_steps(cross, B, T, chunk, out_dtype=out_dtype)
         kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
-        out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
-        L.check(L.load().avi_faceformer_decode_chunked(C.byref(self.cw), cross.data_ptr(), B, T, chunk, kv.data_ptr(),
-                                                       out.data_ptr(), L.stream_ptr()), "avi_faceformer_decode_chunked")
+        out = torch.empty((B, T, self.V), dtype=out_dtype, device=self.device)
+        fn = L.load().avi_faceformer_decode_chunked_f16 if out_dtype == torch.float16 else L.load().avi_faceformer_decode_chunked
+        L.check(fn(C.byref(self.cw), cross.data_ptr(), B, T, chunk, kv.data_ptr(), out.data_ptr(), L.stream_ptr()),
+                "avi_faceformer_decode_chunked")
         return out
 
-    def _decode_steps(self, cross, B, T, chunk, rows_per_call=32):
+    def _decode_steps(self, cross, B, T, chunk, rows_per_call=32, out_dtype=torch.float32):
         """Wide decoders: the per-frame launch chain, one hipGraph per (rows, T, chunk) over static buffers, replayed
         for every block of up to 32 utterances."""
-        out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, T, self.V), dtype=out_dtype, device=self.device)
         so = L.load()
+        entry = so.avi_faceformer_decode_steps_f16 if out_dtype == torch.float16 else so.avi_faceformer_decode_steps
         for b0 in range(0, B, rows_per_call):
             nb = min(rows_per_call, B - b0)
-            key = (nb, T, chunk)
+            key = (nb, T, chunk, out_dtype)
             g = self._graphs.pop(key, None)
             if g is not None:
                 self._graphs[key] = g                # most recently used last
@@ -204,10 +209,10 @@ class Faceformer:
                 st = dict(cross=torch.empty((nb, T, self.D), dtype=torch.float32, device=self.device),
                           kv=torch.empty((nb, T, 2 * self.D), dtype=torch.float32, device=self.device),
                           work=torch.zeros(n.value, dtype=torch.float32, device=self.device),
-                          out=torch.empty((nb, T, self.V), dtype=torch.float32, device=self.device))
+                          out=torch.empty((nb, T, self.V), dtype=out_dtype, device=self.device))
 
                 def chain():
-                    L.check(so.avi_faceformer_decode_steps(C.byref(self.cw), C.byref(self.planes), st["cross"].data_ptr(),
+                    L.check(entry(C.byref(self.cw), C.byref(self.planes), st["cross"].data_ptr(),
                                                            nb, T, chunk, st["kv"].data_ptr(), st["work"].data_ptr(),
                                                            st["out"].data_ptr(), L.stream_ptr()),
                             "avi_faceformer_decode_steps")

@@ -48,11 +48,12 @@ def device_streams(device):
 
 class SamplingPipeline:
     def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None,
-                 rng_seed=None):
+                 rng_seed=None, out_dtype=torch.float32):
         """``rng_seed``: draw the DDPM noise INSIDE the pass from the library's device-resident Philox stream (host/rng.py)
         whenever a call passes ``noise=None`` - the reference draws it inside its loop (models/diffusion_prior.py:337,
         349-351); a captured pass then draws fresh noise at every replay.  None = the caller supplies the noise tensor."""
         self.device = torch.device(device)
+        self.out_dtype = out_dtype         # float16: the head's last kernel stores the coefficients as IEEE half (configs[4])
         from .rng import DeviceRng
         self.rng = None if rng_seed is None else DeviceRng(rng_seed, self.device)
         self._noise_buf = None
@@ -128,7 +129,7 @@ class SamplingPipeline:
         """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside
         the pass, ``rng_seed``) -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
         feat, style = self._body(pcm, voxel, noise)
-        out = self.talking_head.head(feat, style)
+        out = self.talking_head.head(feat, style, out_dtype=self.out_dtype)
         out["style_emb"] = style
         return out
 
@@ -180,7 +181,7 @@ class SamplingPipeline:
         self._h_feat, self._h_style = torch.empty_like(self._feat), torch.empty_like(self._style)
         self._g_head = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_head):       # pools are NOT shared: the two graphs run concurrently
-            self._pout = self.talking_head.head(self._h_feat, self._h_style)
+            self._pout = self.talking_head.head(self._h_feat, self._h_style, out_dtype=self.out_dtype)
             self._pout["style_emb"] = self._h_style
 
         def copy(src, dst):

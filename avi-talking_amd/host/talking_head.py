@@ -122,8 +122,9 @@ class EmoteHead:
             raise ValueError(f"condition has {o} features, the style map expects {self.cond_dim}")
         return ops.linear(cond, self.cond, prec=self.prec)
 
-    def flint_decoder(self, z):
-        """L2lDecoder.forward (L2lMotionPrior.py:460-495): z (B,Tl,256) -> (B,8*Tl,53)."""
+    def flint_decoder(self, z, out_dtype=torch.float32):
+        """L2lDecoder.forward (L2lMotionPrior.py:460-495): z (B,Tl,256) -> (B,8*Tl,53); ``out_dtype`` float16: the last
+        layer's epilogue stores the coefficients as IEEE half."""
         B, Tl, _ = z.shape
         P = self.prec
         zp = ops.pad_repeat(z, 1, 1, 1, 0)
@@ -143,10 +144,11 @@ class EmoteHead:
         x = ops.linear(x, self.lin, prec=P)
         x = self.tel(x, bias_mode=1, slopes=self.slopes)
         xp = ops.pad_repeat(x, 1, 2, 2, 0)
-        return ops.conv1d_cl(xp, self.smooth, 5, 1, prec=P)
+        return ops.conv1d_cl(xp, self.smooth, 5, 1, prec=P, out_dtype=out_dtype)
 
-    def forward(self, audio_feature, style_emb):
-        """audio_feature (B,T,768), style_emb (B,1,128)/(B,128)/(B,T,128) -> dict with predicted_exp/jaw."""
+    def forward(self, audio_feature, style_emb, out_dtype=torch.float32):
+        """audio_feature (B,T,768), style_emb (B,1,128)/(B,128)/(B,T,128) -> dict with predicted_exp/jaw (``out_dtype``
+        float32, or float16 for long-form batches: BASELINE.json configs[4] "fp16 coeffs")."""
         B, T, _ = audio_feature.shape
         P = self.prec
         h = ops.linear(audio_feature, self.seq_enc, prec=P)
@@ -163,7 +165,7 @@ class EmoteHead:
         # one batched launch + the partial-sum epilogue take a third of that
         z = ops.linear_ln_skinny(dp.view(B, T_pad // LATENT_FRAME, LATENT_FRAME * 256), self.squash, do_ln=False,
                                  prec=P)
-        seq = self.flint_decoder(z)[:, :T]
+        seq = self.flint_decoder(z, out_dtype)[:, :T]
         return {"seq_encoder_output": h, "latent": z,
                 "predicted_exp": seq[..., :N_EXP], "predicted_jaw": seq[..., N_EXP:N_EXP + N_JAW]}
 

@@ -33,6 +33,7 @@ class AviGemm(C.Structure):
         ("act", _i), ("prec", _i),
         ("Ahi", _vp), ("Alo", _vp), ("Chi", _vp), ("Clo", _vp),
         ("ldw", _i), ("cus", _i),
+        ("C16", _vp),
     ]
 
 
@@ -148,6 +149,8 @@ SIGNATURES = {
     "avi_prior_time_table": [_vp, _vp, _vp],
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_faceformer_decode_chunked": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "avi_faceformer_decode_chunked_f16": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "avi_faceformer_decode_steps_f16": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "avi_rng_fill": [_vp, C.c_uint, _i, _f, _ll, _vp, _vp],
     "avi_rng_advance": [_vp, C.c_ulonglong, _vp],
     "avi_faceformer_tf_embed": [_vp, _vp, _i, _i, _vp, _vp],

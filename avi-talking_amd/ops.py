@@ -105,13 +105,14 @@ class PackedWeight:
 
 def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
              prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0),
-             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0, cus=0):
+             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0, cus=0, C16=0):
     """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets).  ``cus``: compute units the
     launch can count on (0 = all 256): the sampling pipeline passes what the sampler's resident workgroups leave, so that
     the plane-operand kernels pick tile shapes that fill whole rounds of the CUs that are actually free (AviGemm.cus)."""
     g = L.AviGemm()
     g.ldw = ldw
     g.cus = cus
+    g.C16 = C16 or None
     g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
     g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
@@ -148,7 +149,7 @@ def linear(x, pw, out=None, act=ACT_NONE, residual=None, prec=PREC_BF16X3, scale
 
 
 def conv1d_cl(x, pw, ksize, stride, out=None, act=ACT_NONE, prec=PREC_BF16X3, scale=None, shift=None,
-              out_rows=None, out_row_stride=None, out_offset=0, in_row_offset=0):
+              out_rows=None, out_row_stride=None, out_offset=0, in_row_offset=0, out_dtype=torch.float32):
     """Channels-last Conv1d without padding as an overlapping-row GEMM.
 
     x [B][Tin][Cin]; weight packed as [Cout][k*Cin] (tap-major); out [B][Tout][Cout] with
@@ -163,9 +164,15 @@ def conv1d_cl(x, pw, ksize, stride, out=None, act=ACT_NONE, prec=PREC_BF16X3, sc
     Tout = (Tin - in_row_offset - ksize) // stride + 1
     if Tout <= 0:
         raise ValueError("conv1d_cl: input shorter than the kernel")
+    half = out_dtype == torch.float16           # the result stored as IEEE half by the GEMM's own epilogue (AviGemm.C16)
     if out is None:
-        out = torch.empty((B, Tout, pw.N), dtype=torch.float32, device=x.device)
-    _f32c(out, "out")
+        out = torch.empty((B, Tout, pw.N), dtype=out_dtype, device=x.device)
+    if half:
+        if out.dtype != torch.float16 or not out.is_contiguous():
+            raise ValueError("conv1d_cl: out_dtype float16 needs a contiguous float16 out")
+        L.require_gpu(out)
+    else:
+        _f32c(out, "out")
     rows = Tout if out_rows is None else out_rows
     if rows > Tout:
         raise ValueError("conv1d_cl: more output rows requested than the input provides")
@@ -173,8 +180,9 @@ def conv1d_cl(x, pw, ksize, stride, out=None, act=ACT_NONE, prec=PREC_BF16X3, sc
     per_b = out.numel() // B
     if out_offset + (rows - 1) * ldc + pw.N > per_b:
         raise ValueError("conv1d_cl: output rows exceed the out buffer")
+    c_args = dict(C16=out.data_ptr() + 2 * out_offset) if half else dict(C_=out.data_ptr() + 4 * out_offset)
     gemm_raw(A=x.data_ptr() + 4 * in_row_offset * Cin, lda=stride * Cin, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(),
-             C_=out.data_ptr() + 4 * out_offset, ldc=ldc, M=rows, N=pw.N, K=pw.K, bias=L.ptr(pw.bias),
+             ldc=ldc, M=rows, N=pw.N, K=pw.K, bias=L.ptr(pw.bias), **c_args,
              scale=L.ptr(scale), shift=L.ptr(shift), act=act, prec=prec, batch=B, z_inner=1,
              sA=(Tin * Cin, 0), sC=(per_b, 0))
     return out

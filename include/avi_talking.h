@@ -87,6 +87,10 @@ typedef struct AviGemm {
      * whole duration (the sampling pipeline: 32 sampler workgroups) passes the remainder, and the tile shape is chosen
      * to fill whole rounds of THAT many workgroups. */
     int cus;
+    /* Optional IEEE-half copy of the result (fp32-operand kernel only: A set, Ahi NULL), same ldc / batch strides as C,
+     * counted in elements; C may then be NULL.  The EMOTE head's last layer writes its coefficients this way for long-form
+     * batches (BASELINE.json configs[4]: "fp16 coeffs"): half the bytes, |rounding| <= 2^-11 |value|. */
+    uint16_t* C16;
 } AviGemm;
 int avi_gemm(const AviGemm* g, void* stream);
 
@@ -305,6 +309,10 @@ int avi_faceformer_decode(const AviFaceformerWeights* w, const float* cross, int
  * predict_cached(chunk=...). */
 int avi_faceformer_decode_chunked(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
                                   float* kv_scratch, float* out, void* stream);
+/* Same decode, the (un-normalised) coefficients stored as IEEE half [B][T][V] (configs[4] "fp16 coeffs"); the fed-back
+ * frame stays fp32, so the decode itself is unchanged and out16 == half(out) element by element. */
+int avi_faceformer_decode_chunked_f16(const AviFaceformerWeights* w, const float* cross, int B, int T, int chunk,
+                                      float* kv_scratch, uint16_t* out16, void* stream);
 
 /* Input rows of the TEACHER-FORCED decoder pass (models/faceformer.py:382-384): out[b][t] = vertice_map(coeff[b][t-1]) +
  * pe[t mod period] with coeff[b][-1] = 0 (`torch.cat([zeros_like(coeff[:, -1:]), coeff[:, :-1]], 1)`), coeff [B][T][V]
@@ -334,6 +342,8 @@ int avi_faceformer_steps_work_floats(int D, int B, long long* floats);
 /* Enqueues the whole chain on `stream`.  D a multiple of 64 with D/4 in {16,...,256}; B <= 32 per call. */
 int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
                                 int B, int T, int chunk, float* kv_scratch, float* work, float* out, void* stream);
+int avi_faceformer_decode_steps_f16(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
+                                    int B, int T, int chunk, float* kv_scratch, float* work, uint16_t* out16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training step (aligner + prior; train_diffusion_prior.py:434-499).  Backward GEMMs reuse avi_gemm:

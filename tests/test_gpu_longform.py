@@ -60,3 +60,42 @@ def test_faceformer_chunked_causal_60s(gpu, monkeypatch, steps, D):
     # the first chunk is the reference's own decode of the first 600 frames
     ref600 = OF.predict_cached(w, hs[:, :600], 30)
     assert (out[:, :600] - ref600).abs().max().item() < 1e-3
+
+
+def test_fp16_coefficient_output_head(gpu):
+    """BASELINE configs[4] "fp16 coeffs": the EMOTE/FLINT head's LAST kernel stores the coefficients as IEEE half
+    (AviGemm.C16).  Every element is the fp32 result rounded once: |half - fp32| <= 2^-11 |fp32| (half has 11 significant
+    bits; subnormals below 6e-5 get an absolute 2^-25), and it equals torch's own rounding of the fp32 tensor."""
+    from avi_talking_amd.weights import make_emote_weights
+    from avi_talking_amd.host.talking_head import EmoteHead
+    g = torch.Generator().manual_seed(31)
+    B, T = 3, 333                                           # T not a multiple of 8: padded and cropped
+    feat, style = torch.randn(B, T, 768, generator=g).to(gpu), (torch.randn(B, 1, 128, generator=g) * 0.5).to(gpu)
+    head = EmoteHead(make_emote_weights(1), device=gpu)
+    f32 = head(feat, style)
+    f16 = head(feat, style, out_dtype=torch.float16)
+    for k in ("predicted_exp", "predicted_jaw"):
+        a, h = f32[k], f16[k]
+        assert h.dtype == torch.float16 and h.shape == a.shape
+        assert torch.equal(h, a.to(torch.float16))
+        assert ((h.float() - a).abs() <= a.abs() * 2.0 ** -11 + 2.0 ** -25).all()
+
+
+@pytest.mark.parametrize("D,steps", [(64, "0"), (256, "1")])
+def test_fp16_coefficient_output_faceformer(gpu, monkeypatch, D, steps):
+    """Both FaceFormer device paths with half output (un-normalised coefficients): element by element the rounded fp32
+    decode - the fed-back frame stays fp32, so the recursion itself is unchanged."""
+    import os
+    import numpy as np
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    monkeypatch.setenv("AVI_FF_STEPS", steps)
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mean, std = np.load(os.path.join(G, "coeff_mean.npy")), np.load(os.path.join(G, "coeff_std.npy"))
+    ff = Faceformer(make_faceformer_weights(2, feature_dim=D), period=30, device=gpu, coeff_mean=mean, coeff_std=std)
+    hs = torch.randn(2, 700, D, generator=torch.Generator().manual_seed(72)).to(gpu)
+    a = ff.decode(hs, chunk=600)
+    h = ff.decode(hs, chunk=600, out_dtype=torch.float16)
+    assert h.dtype == torch.float16 and torch.equal(h, a.to(torch.float16))
+    with pytest.raises(ValueError):
+        ff.decode(hs, chunk=600, out_dtype=torch.bfloat16)
