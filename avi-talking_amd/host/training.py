@@ -82,10 +82,13 @@ def grad_spans(depth=6, n_blocks=4):
     no-decay tail [n_decay, numel) they cover the flat gradient buffer exactly once
     (tests/test_dist_gloo.py::test_grad_spans_cover_flat_buffer_once)."""
     v, c = "voxel2clip.", "net.causal_transformer."
-    spans = [("net.to_time_embeds.0.1.net.0.0.weight", c + "project_out.weight"),      # the whole prior network
-             (v + "lin1.weight", v + "projector.8.weight")]
-    spans += [(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight") for b in reversed(range(n_blocks))]
+    # the four 67 MB aligner blocks first (97 % of the volume): backward reaches them as soon as the dX chain of the prior
+    # and of the projector has produced their incoming gradient - the parameter gradients of the prior, the projector and
+    # lin1 (leaves of backward) are formed AFTER them, under the blocks' all-reduces
+    spans = [(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight") for b in reversed(range(n_blocks))]
     spans.append((v + "lin0.0.weight", v + "lin0.1.weight"))
+    spans.append((v + "lin1.weight", v + "projector.8.weight"))
+    spans.append(("net.to_time_embeds.0.1.net.0.0.weight", c + "project_out.weight"))   # the whole prior network
     return spans
 
 
@@ -114,26 +117,39 @@ class GradSync:
         import torch.distributed as dist
         return self.world() > 1 or (self.force and dist.is_available() and dist.is_initialized())
 
-    def ready(self, G, first, last):
+    def ready(self, G, first, last, launch=True):
+        """``launch=False``: bookkeeping only (the segment capture of the DP step walks the announcements without
+        issuing collectives)."""
         span = self.layout.span(first, last)
         i = len(self.done)
         if i >= len(self.expected) or span != self.expected[i]:
             raise RuntimeError(f"gradient span {first}..{last} announced out of order (position {i})")
         self.done.append(span)
-        if self._collectives():
+        if launch and self._collectives():
             self.works += bucketed_allreduce(G, [span], self.pg)
 
-    def finish(self, G):
-        """Reduce the no-decay tail, wait for every bucket; returns the world size (AdamW scales by 1/world)."""
+    def finish(self, G, launch=True, on_span=None):
+        """Reduce the no-decay tail, wait for every bucket; returns the world size (AdamW scales by 1/world).
+        ``on_span(a, b)``: called for every span [a, b) of the flat buffer - the announced ones in announcement order, then
+        the tail - as soon as ITS all-reduce has been waited for on the current stream (the optimizer updates a bucket
+        while later buckets are still on the wire)."""
         if len(self.done) != len(self.expected):
             raise RuntimeError(f"{len(self.expected) - len(self.done)} gradient spans were never announced")
+        spans = self.done + [(self.layout.n_decay, self.layout.numel)]
         self.done = []
         world = self.world()
-        if self._collectives():
+        works = []
+        if launch and self._collectives():
             L_ = self.layout
             self.works += bucketed_allreduce(G, [(L_.n_decay, L_.numel)], self.pg)
-            for w in self.works:
-                w.wait()
+            works = self.works
+            if len(works) != len(spans):
+                raise RuntimeError("one collective per gradient span expected")
+        for i, span in enumerate(spans):
+            if works:
+                works[i].wait()
+            if on_span is not None:
+                on_span(*span)
         self.works = []
         return world
 
@@ -196,6 +212,14 @@ class _Lin:
 
     def bwd(self, x, dy, dx_residual=None):
         """Accumulate nothing: writes dW (and db) into the flat gradient buffer, returns dx (+ residual)."""
+        self.bwd_dw(x, dy)
+        if not self.need_dx:
+            return None
+        return self.bwd_dx(dy, dx_residual)
+
+    def bwd_dw(self, x, dy):
+        """dW = dy^T x (and db = column sums of dy) into the flat gradient buffer.  A leaf of the backward pass: callers
+        may run it any time after ``dy`` exists (the data-parallel step orders these launches by bucket size)."""
         so = L.load()
         M = dy.numel() // self.N
         if M % 64:
@@ -214,9 +238,6 @@ class _Lin:
         L.check(so.avi_transpose_jobs(jobs, 3 if self.b else 2, L.stream_ptr()), "avi_transpose_jobs")
         ops.gemm_raw(A=dyT.data_ptr(), lda=M, Whi=xhi.data_ptr(), Wlo=xlo.data_ptr(),
                      C_=self.s.gptr(self.w), ldc=self.K, M=self.N, N=self.K, K=M)
-        if not self.need_dx:
-            return None
-        return self.bwd_dx(dy, dx_residual)
 
     def bwd_dx(self, dy, dx_residual=None):
         """dx = dy . W (+ residual) alone: the parameter gradient of this layer is formed elsewhere (the prior's layers
@@ -339,6 +360,7 @@ class PriorTrainer:
         self.rel_index = dv(torch.clamp(q - k, min=0))                        # (3,4) bucket of each (i,j)
         self.dyn = torch.zeros(4, dtype=torch.float32, device=self.device)   # lr, bc1, rsqrt(bc2) for the graph
         self.sync = GradSync(S.layout, depth, n_blocks, process_group)
+        self._cut = None
         self._ttable = None
         self._ws = {}
         import os
@@ -355,7 +377,10 @@ class PriorTrainer:
         """Called as soon as the backward pass has finished writing the decay-region gradients from parameter
         ``first`` through ``last`` (contiguous in the flat buffer): start their all-reduce now, so it overlaps
         with the rest of backward (the 67 M-parameter aligner blocks dominate the 311 MB volume)."""
-        self.sync.ready(self.store.G, first, last)
+        if self._cut is not None:                 # segment capture (capture_step_dp): end a graph here, start the next
+            self._cut(first, last)
+        else:
+            self.sync.ready(self.store.G, first, last)
 
     # ------------------------------------------------------------------ deferred parameter gradients of the prior layers
     _DW = (("qkv", 640, DIM), ("out", DIM, 512), ("w1", 1024, DIM), ("w2", DIM, 512))     # (lin, N out, K in)
@@ -719,14 +744,41 @@ class PriorTrainer:
                                               dqkv.data_ptr(), S.gptr(a + "null_kv"), drel.data_ptr(), st()), "attn_bwd")
                 dn1 = ly["qkv"].bwd_dx(dqkv)
                 dtok = self._ln_bwd(tk, dn1, a + "norm.g", dx_add=dtokm, out=ws["w2"]["dy"][li - 1] if li > 0 else None)
-        self._deferred_dw(ws, R)
-        # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
-        L.check(so.avi_prior_rel_bias(None, None, drel.data_ptr(), S.gptr(rel_name), 8, 3, st()), "rel_bias_bwd")
         dtext = torch.empty((B, DIM), dtype=torch.float32, device=dev)
         dtemb = torch.empty((B, DIM), dtype=torch.float32, device=dev)
         L.check(so.avi_prior_tokens_bwd(dtok.data_ptr(), L.ptr(bk), L.ptr(ik), B, dtext.data_ptr(), dtemb.data_ptr(),
                                         S.gptr("net.null_brain_embeds"), S.gptr("net.null_image_embed"),
                                         S.gptr("net.learned_query"), st()), "tokens_bwd")
+
+        # ---- BrainNetwork backward.  Order = what the data-parallel step wants (results do not depend on it: every
+        # gradient element is still produced once, by the same launch on the same operands): first the dX chain down to the
+        # four residual blocks - their 4096 x 4096 matrices are 97 % of the gradient bytes, each block's bucket starts its
+        # all-reduce the moment its dW is written - and only then the parameter gradients that are leaves of backward
+        # (projector, lin1, the prior's layers, the time MLP), which run under those all-reduces.
+        dz2 = self.proj[2].bwd_dx(dproj)
+        dz2p = self._ln_bwd(z2p, dz2, v + "projector.6.weight", v + "projector.6.bias", ops.ACT_GELU)
+        dz1 = self.proj[1].bwd_dx(dz2p)
+        dz1p = self._ln_bwd(z1p, dz1, v + "projector.3.weight", v + "projector.3.bias", ops.ACT_GELU)
+        dz0 = self.proj[0].bwd_dx(dz1p)
+        dout = self._ln_bwd(out, dz0, v + "projector.0.weight", v + "projector.0.bias", ops.ACT_GELU, dx_add=dtext)
+        dh = self.lin1.bwd_dx(dout)
+        for b in reversed(range(self.n_blocks)):
+            dyp = self._ln_bwd(yp[b], dh, v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias", ops.ACT_GELU, dm[b + 1])
+            dh = self.mlp[b].bwd(h[b], dyp, dx_residual=dh)
+            self._grads_ready(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight")
+        dh0p = self._ln_bwd(h0p, dh, v + "lin0.1.weight", v + "lin0.1.bias", ops.ACT_GELU, dm[0])
+        self.lin0.bwd(x, dh0p)
+        self._grads_ready(v + "lin0.0.weight", v + "lin0.1.weight")
+        self.proj[2].bwd_dw(z2, dproj)
+        self.proj[1].bwd_dw(z1, dz2p)
+        self.proj[0].bwd_dw(z0, dz1p)
+        self.lin1.bwd_dw(h[-1], dout)
+        self._grads_ready(v + "lin1.weight", v + "projector.8.weight")
+
+        # ---- leaves of the prior's backward: the 24 layer matrices (batched launches), the T5 bias table, the time MLP
+        self._deferred_dw(ws, R)
+        # scatter the (8,3,4) bias gradient back onto the (32,8) T5 bucket table
+        L.check(so.avi_prior_rel_bias(None, None, drel.data_ptr(), S.gptr(rel_name), 8, 3, st()), "rel_bias_bwd")
         da2 = self.tm[2].bwd(a2, dtemb)
         da2p = torch.empty_like(a2p)
         L.check(so.avi_act_bwd(a2p.data_ptr(), da2.data_ptr(), a2p.numel(), ops.ACT_SILU, da2p.data_ptr(), st()), "act_bwd")
@@ -735,23 +787,6 @@ class PriorTrainer:
         L.check(so.avi_act_bwd(a1p.data_ptr(), da1.data_ptr(), a1p.numel(), ops.ACT_SILU, da1p.data_ptr(), st()), "act_bwd")
         self.tm[0].bwd(te0, da1p)
         self._grads_ready("net.to_time_embeds.0.1.net.0.0.weight", self.c + "project_out.weight")
-
-        # ---- BrainNetwork backward
-        dz2 = self.proj[2].bwd(z2, dproj)
-        dz2p = self._ln_bwd(z2p, dz2, v + "projector.6.weight", v + "projector.6.bias", ops.ACT_GELU)
-        dz1 = self.proj[1].bwd(z1, dz2p)
-        dz1p = self._ln_bwd(z1p, dz1, v + "projector.3.weight", v + "projector.3.bias", ops.ACT_GELU)
-        dz0 = self.proj[0].bwd(z0, dz1p)
-        dout = self._ln_bwd(out, dz0, v + "projector.0.weight", v + "projector.0.bias", ops.ACT_GELU, dx_add=dtext)
-        dh = self.lin1.bwd(h[-1], dout)
-        self._grads_ready(v + "lin1.weight", v + "projector.8.weight")
-        for b in reversed(range(self.n_blocks)):
-            dyp = self._ln_bwd(yp[b], dh, v + f"mlp.{b}.1.weight", v + f"mlp.{b}.1.bias", ops.ACT_GELU, dm[b + 1])
-            dh = self.mlp[b].bwd(h[b], dyp, dx_residual=dh)
-            self._grads_ready(v + f"mlp.{b}.0.weight", v + f"mlp.{b}.1.weight")
-        dh0p = self._ln_bwd(h0p, dh, v + "lin0.1.weight", v + "lin0.1.bias", ops.ACT_GELU, dm[0])
-        self.lin0.bwd(x, dh0p)
-        self._grads_ready(v + "lin0.0.weight", v + "lin0.1.weight")
         return {"loss_prior": losses[0:1], "loss_nce": losses[1:2], "pred": pred, "proj": proj, "clip_voxels": out}
 
     # ------------------------------------------------------------------ optimizer
@@ -788,6 +823,95 @@ class PriorTrainer:
                                      1.0 / world, dyn, S.HI.data_ptr() + 2 * lo, S.LO.data_ptr() + 2 * lo,
                                      L.stream_ptr()), "adamw")
         self.refresh()
+
+    def _adamw_span(self, a, b, world, lr=None, beta1=None, use_dyn=False):
+        """Fused AdamW over [a, b) of the flat buffers (one gradient bucket): decay iff the span lies in the decay region."""
+        S = self.store
+        b1, b2 = self.betas
+        b1 = b1 if beta1 is None else float(beta1)
+        wd = self.wd if b <= S.n_decay else 0.0
+        if a < S.n_decay < b:
+            raise ValueError("a gradient span must not straddle the decay / no-decay boundary")
+        L.check(L.load().avi_adamw(S.P.data_ptr() + 4 * a, S.G.data_ptr() + 4 * a, S.M.data_ptr() + 4 * a,
+                                   S.V.data_ptr() + 4 * a, b - a, self.lr if lr is None else lr, b1, b2, self.eps, wd,
+                                   max(self.step_count, 1), 1.0 / world, self.dyn.data_ptr() if use_dyn else 0,
+                                   S.HI.data_ptr() + 2 * a, S.LO.data_ptr() + 2 * a, L.stream_ptr()), "adamw")
+
+    # ------------------------------------------------------------------ data-parallel step as hipGraph segments
+    def capture_step_dp(self, voxel, clip_target, temp, rand=None, warmup=2, rng=None):
+        """The data-parallel step (train_diffusion_prior.py:338,442,450 are the reference's dead ``distributed`` branches)
+        as a chain of hipGraph SEGMENTS: forward + backward are cut at the gradient-bucket announcements (``_grads_ready``:
+        four aligner blocks, lin0, lin1 + projector, the prior network), the bucket's RCCL all-reduce is issued eagerly
+        between two segments - collectives stay outside the graphs - and runs on RCCL's stream beside the next segment;
+        after the last segment every bucket is waited for in turn and updated by its own fused-AdamW launch, so the
+        optimizer works on the first buckets while the last ones are still on the wire.  ~140 launches per step become 7
+        graph replays + 8 all-reduces + 9 launches.  Works with any world size (world 1 = the same chain without
+        collectives; AVI_DP_FORCE_COLLECTIVES=1 issues them over one rank: the rehearsal a one-GPU box allows)."""
+        if rand is None:
+            if rng is None:
+                raise ValueError("capture_step_dp needs rand (recorded draws) or rng (in-graph draws)")
+            rand = self.draw(voxel.shape[0])
+        self._static = dict(voxel=voxel.clone(), target=clip_target.clone(),
+                            rand={k: ([m.clone() for m in v] if isinstance(v, list) else v.clone())
+                                  for k, v in rand.items()})
+        st = self._static
+
+        def fb():
+            r = st["rand"]
+            if rng is not None:
+                self.draw_device(rng, r)
+            return self.forward_backward(st["voxel"], st["target"], r["times"], r["noise"], temp, r["brain_keep"],
+                                         r["image_keep"], r["dropout_masks"])
+
+        for _ in range(warmup):                              # eager steps (with collectives when there are ranks)
+            fb()
+            world = self.sync.finish(self.store.G)
+            self.optimizer_step(world=world, use_dyn=True)
+        torch.cuda.synchronize(self.device)
+        self._segs = []
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream(device=self.device)
+        cur = {"g": None}
+        n_spans = len(self.sync.expected)
+
+        def begin():
+            cur["g"] = torch.cuda.CUDAGraph()
+            # thread_local: the process group's watchdog thread may query events while a segment is being captured
+            cur["g"].capture_begin(pool=pool, capture_error_mode="thread_local")
+
+        def cut(first, last):
+            cur["g"].capture_end()
+            self._segs.append((cur["g"], (first, last)))
+            self.sync.ready(self.store.G, first, last, launch=False)        # order / coverage checks still run
+            if len(self._segs) < n_spans:
+                begin()
+
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(stream):
+            self._cut = cut
+            try:
+                begin()
+                self._gout = fb()
+            finally:
+                self._cut = None
+        torch.cuda.current_stream(self.device).wait_stream(stream)
+        if len(self._segs) != n_spans:
+            raise RuntimeError("the backward pass announced fewer gradient spans than the layout expects")
+        self.sync.finish(self.store.G, launch=False)
+        torch.cuda.synchronize(self.device)
+        return self
+
+    def replay_step_dp(self, lr=None, beta1=None):
+        self.step_count += 1
+        self._set_dyn(self.lr if lr is None else lr, beta1)
+        G = self.store.G
+        for graph, (first, last) in self._segs:
+            graph.replay()
+            self.sync.ready(G, first, last)                   # eager all-reduce of the bucket this segment completed
+        world = self.sync.world()
+        self.sync.finish(G, on_span=lambda a, b: self._adamw_span(a, b, world, use_dyn=True))
+        self.refresh()
+        return self._gout
 
     def train_step(self, voxel, clip_target, temp, rand=None, lr=None, beta1=None):
         """``lr`` / ``beta1``: this step's rate and AdamW beta1 (``OneCycleLR.lr_at`` / ``momentum_at``); None = the

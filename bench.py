@@ -385,14 +385,21 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
     target = torch.randn(B, 1, 128, device=dev, generator=g) * 0.3
     rand = tr.draw(B, generator=g)
     temp = 0.005
-    graph = world == 1 and dist is None and not args.no_graph      # collectives stay outside a captured step
-    if graph:
-        # times / noise / cond-drop masks / dropout masks are drawn inside the captured step (train_diffusion_prior.py:449)
-        from avi_talking_amd.host.rng import DeviceRng
+    from avi_talking_amd.host.rng import DeviceRng
+    # times / noise / cond-drop masks / dropout masks are drawn inside the captured step (train_diffusion_prior.py:449)
+    if args.no_graph:
+        graph = False
+        step = lambda: tr.train_step(voxel, target, temp, rand=rand)
+    elif dist is None:
+        graph = "one graph"
         tr.capture_step(voxel, target, temp, rng=DeviceRng(4321 + rank, dev))
         step = tr.replay_step
     else:
-        step = lambda: tr.train_step(voxel, target, temp, rand=rand)
+        # data parallel: hipGraph segments cut at the gradient-bucket announcements, the RCCL all-reduces issued eagerly
+        # between them (collectives stay outside the graphs), one fused-AdamW launch per bucket as its sum arrives
+        graph = "segments (7 graphs) + eager RCCL all-reduce per bucket + per-bucket AdamW"
+        tr.capture_step_dp(voxel, target, temp, rng=DeviceRng(4321 + rank, dev))
+        step = tr.replay_step_dp
     for _ in range(3):
         out = step()
     torch.cuda.synchronize(dev)
@@ -421,6 +428,7 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
             "allreduce_mb": round(tr.store.numel * 4 / 1e6, 1) if world > 1 else 0, "hipgraph": graph,
             "random_draws": "inside the captured step (Philox stream: times, noise, cond-drop and dropout masks)" if graph
                             else "recorded tensors",
+            "gradient_buckets": [f"{a}..{b}" for a, b in __import__("avi_talking_amd.host.training", fromlist=["x"]).grad_spans()] if world > 1 else None,
             "dtype": "bf16x3", "loss_prior": round(lp, 5), "loss_nce": round(ln, 5)}
 
 

@@ -186,6 +186,45 @@ def test_trainer_gradient_sync_world2_matches_single_process():
     assert err < 2e-5 * expect.abs().max().item()
 
 
+def _span_update_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd.host.training import FlatLayout, GradSync, _layout, grad_spans
+    from avi_talking_amd.weights import make_prior_weights
+    lay = FlatLayout.of_state_dict(make_prior_weights(3), _layout())
+    G = torch.full((lay.numel,), float(rank + 1))
+    P = torch.zeros(lay.numel)
+    sync = GradSync(lay)
+    for a, b in grad_spans():
+        sync.ready(G, a, b)
+    seen = []
+
+    def update(a, b):                        # what PriorTrainer.replay_step_dp does per bucket: its own optimizer launch
+        assert bool((G[a:b] == 3.0).all()), "a bucket was handed to the optimizer before its sum had arrived"
+        P[a:b] += G[a:b] / world
+        seen.append((a, b))
+    sync.finish(G, on_span=update)
+    if rank == 0:
+        ret["seen"], ret["P"] = seen, P.clone()
+        ret["expected"] = [lay.span(a, b) for a, b in grad_spans()] + [(lay.n_decay, lay.numel)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_bucket_optimizer_callback_world2():
+    """GradSync.finish(on_span=...): every span of the flat buffer - the announced buckets in announcement order, then the
+    no-decay tail - is handed to the optimizer exactly once and only after ITS all-reduce has completed (world 2, gloo)."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_span_update_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["seen"] == ret["expected"]
+    covered = torch.zeros_like(ret["P"])
+    for a, b in ret["seen"]:
+        covered[a:b] += 1
+    assert bool((covered == 1).all())
+    assert bool((ret["P"] == 1.5).all())
+
+
 # ----------------------------------------------------------------------------- bench.py launcher
 def test_bench_gpus_flag_spawns_ranks_dry_run():
     """`python bench.py --gpus 2` with no launcher in the environment starts 2 ranks itself (CPU/gloo rehearsal): one

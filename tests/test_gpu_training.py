@@ -264,3 +264,54 @@ def test_gradient_buffer_needs_no_clearing(gpu):
         worst = int(diff.argmax())
         name = max((n for n in tr.store.names if tr.store.offset[n] <= worst), key=lambda n: tr.store.offset[n])
         assert diff.max().item() <= 1e-5 * ref.abs().max().item(), (name, diff.max().item())
+
+
+def test_dp_segment_step_equals_single_graph_step(gpu, setup):
+    """capture_step_dp (the data-parallel step: 7 hipGraph segments cut at the gradient-bucket announcements, the bucket
+    all-reduces between them, one fused-AdamW launch per bucket) at world size 1 against capture_step (one graph, one AdamW
+    over the whole buffer): same recorded draws, three steps.  The reordering of the backward pass and the per-bucket optimizer
+    change no arithmetic; what is left between two runs of ANY of the two paths is the order of the float atomics that
+    accumulate the null-kv and relative-bias gradients (a few ulps there, which AdamW's m / sqrt(v) turns into a visible
+    fraction of lr on parameters whose gradient is near zero), so the yardstick is the difference between two runs of the
+    single-graph path itself."""
+    from avi_talking_amd.host.training import PriorTrainer, grad_spans
+    voxel, target, times, noise, bk, ik, masks = setup["inputs"]
+    rand = dict(times=times.to(gpu).to(torch.int32), noise=noise.to(gpu), brain_keep=bk.to(gpu), image_keep=ik.to(gpu),
+                dropout_masks=[m.to(gpu) for m in masks])
+    def run(dp):
+        tr = PriorTrainer(setup["w"], device=gpu, lr=1e-3)
+        (tr.capture_step_dp if dp else tr.capture_step)(voxel.to(gpu), target.to(gpu), 0.005, rand, warmup=1)
+        losses = []
+        for k in range(3):
+            o = (tr.replay_step_dp if dp else tr.replay_step)(lr=1e-3 * (k + 1), beta1=0.9 + 0.01 * k)
+            torch.cuda.synchronize()
+            losses.append((float(o["loss_prior"]), float(o["loss_nce"])))
+        return tr, losses
+
+    one, l_one = run(False)
+    again, l_again = run(False)              # the same path twice: the noise floor of the float atomics
+    seg, l_seg = run(True)
+    assert len(seg._segs) == len(grad_spans()) == 7 and one.step_count == seg.step_count == 4
+    for (a0, a1), (b0, b1) in zip(l_one, l_seg):
+        assert abs(a0 - b0) <= 1e-6 * max(1.0, abs(a0)) and abs(a1 - b1) <= 1e-6 * max(1.0, abs(a1))
+    for name in ("P", "M", "V", "G"):
+        x, y, z = getattr(one.store, name), getattr(seg.store, name), getattr(again.store, name)
+        floor = (x - z).abs().max().item()
+        err = (x - y).abs().max().item()
+        print(f"{name}: segments vs one graph {err:.2e}, one graph vs itself {floor:.2e} (scale {x.abs().max().item():.2e})")
+        assert err <= max(4.0 * floor, 1e-7 * x.abs().max().item()), (name, err, floor)
+    recon = seg.store.HI.view(torch.bfloat16).float() + seg.store.LO.view(torch.bfloat16).float()
+    assert (recon - seg.store.P).abs().max().item() <= 2e-5 * seg.store.P.abs().max().item()   # planes follow the update
+
+def test_dp_segment_step_with_in_graph_draws(gpu, setup):
+    """The segment chain with its random draws inside the first segment: replays advance the stream, a reset reproduces."""
+    from avi_talking_amd.host.rng import DeviceRng
+    from avi_talking_amd.host.training import PriorTrainer
+    voxel, target = setup["inputs"][0].to(gpu), setup["inputs"][1].to(gpu)
+    tr = PriorTrainer(setup["w"], device=gpu, lr=1e-4)
+    rng = DeviceRng(5, gpu)
+    tr.capture_step_dp(voxel, target, 0.005, rng=rng, warmup=1)
+    rng.set_state(offset=10)
+    l0 = float(tr.replay_step_dp()["loss_prior"])
+    l1 = float(tr.replay_step_dp()["loss_prior"])
+    assert rng.get_state() == (5, 12) and l0 == l0 and l1 == l1 and l0 != l1
