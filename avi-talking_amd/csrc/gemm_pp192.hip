@@ -21,6 +21,8 @@
 //   * the K loop is unrolled by three K tiles so every LDS offset is an immediate (K tiles must come in threes:
 //     K % 96 == 0 in bf16x3, K % 192 == 0 in bf16); past the end of K the issue slots reload the last K tile.
 //   * epilogue: per-wave LDS transposition (64 rows x 48 columns, row stride 208 B), then 16-B stores along rows.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -54,20 +56,53 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 }
 
 // F16 (with NS = 2): the opt-in 2-term fp16 mode AVI_PREC_F16X2, as in gemm_pp.hip.
+// STREAM-K (sk_total > 0; batch 1): the launch is `gridDim.x` workgroups, one per compute unit the caller can count on,
+// and the K loops of ALL tiles - sk_total groups of three K tiles, tile after tile - are cut into gridDim.x equal
+// contiguous shares.  A workgroup walks its share: at most one tile tail, whole tiles, one tile head.  A tile computed
+// by one workgroup takes the ordinary epilogue; a tile shared by several is finished by whichever contributor arrives
+// LAST (no workgroup ever waits for another, so nothing depends on dispatch order or co-residency): every contributor
+// stores its 128 x BN fp32 partial to its own slot of the workspace, releases it (agent scope) and bumps the tile's
+// counter; the one that reads count - 1 acquires, adds the other slots to its registers, runs the epilogue and puts the
+// counter back to zero for the next launch.  M = 8000 on the 224 CUs the sampler leaves gives 189 tiles of 128 x 256
+// (N = 768: 84 % of one round) or 567 (N = 2304: 2.53 rounds = 84 % of three): with equal shares every CU computes
+// 0.84 / 2.53 tiles' worth instead of 1 / 3.
+constexpr int SK_MAXC = 4;     // contributors per tile the workspace has slots for (host: share >= tile K groups / 2)
+
 template <int NS, int NT, bool F16 = false>
-__global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+__global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN,
+                                                          const int sk_total, float* __restrict__ sk_ws,
+                                                          int* __restrict__ sk_cnt) {
     constexpr int BN = Geo<NT>::BN, STAGE_BYTES = Geo<NT>::STAGE_BYTES, EP_STRIDE = Geo<NT>::EP_STRIDE,
                   EP_SLAB = Geo<NT>::EP_SLAB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int sk_last;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int nwg = tilesM * tilesN;
-    int t = blockIdx.x;
+    const int nwg = sk_total ? (int)gridDim.x : tilesM * tilesN;
+    int wg = blockIdx.x;      // XCD-aware, bijective: workgroups b and b + 8 (one XCD) take neighbouring tiles / shares
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nk_all = g.K / (NS == 2 ? 32 : 64);   // multiple of 3 (checked by the launcher)
+    const int G = nk_all / 3;                       // K groups per tile
+    int sk_it = sk_total ? (int)((long long)wg * sk_total / nwg) : 0;
+    const int it_end = sk_total ? (int)((long long)(wg + 1) * sk_total / nwg) : 1;
+  for (;;) {                                        // stream-K: the items of this workgroup's share; else one tile
+    int t, kt0, nk;
+    if (sk_total) {
+        if (sk_it >= it_end) break;
+        t = sk_it / G;
+        const int g0 = sk_it - t * G, g1 = (g0 + it_end - sk_it) < G ? (g0 + it_end - sk_it) : G;
+        kt0 = 3 * g0;
+        nk = 3 * (g1 - g0);
+        sk_it += g1 - g0;
+    } else {
+        t = wg;
+        kt0 = 0;
+        nk = nk_all;
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -95,7 +130,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
         for (int h = 0; h < 2; ++h) {
             int m = m0 + (R >> 5) * 64 + h * 32 + (R & 31);
             m = m < g.M ? m : g.M - 1;
-            xsrc[h] = reinterpret_cast<const char*>(base + (long long)m * g.lda) + off;
+            xsrc[h] = reinterpret_cast<const char*>(base + (long long)m * g.lda) + off + (long long)kt0 * KB;
         }
     }
 #pragma unroll
@@ -106,9 +141,8 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
         const uint16_t* base = (NS == 2 && c >= 4) ? Wlo : Whi;
         int n = n0 + R;
         n = n < g.N ? n : g.N - 1;
-        wsrc[i] = reinterpret_cast<const char*>(base + n * ldw) + off;
+        wsrc[i] = reinterpret_cast<const char*>(base + n * ldw) + off + (long long)kt0 * KB;
     }
-    const int nk = g.K / (NS == 2 ? 32 : 64);   // multiple of 3 (checked by the launcher)
 
     auto issue_w = [&](int T, int stage) __attribute__((always_inline)) {
         const long long kofs = (long long)(T < nk ? T : nk - 1) * KB;
@@ -253,6 +287,43 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();                                               // every wave's tail DMA has landed: the stages are dead
 
+    if (sk_total && nk != nk_all) {                      // ---- stream-K: this workgroup holds a PARTIAL sum of tile t
+        // contributors of tile t = the workgroups whose share holds one of its G groups: first .. last, this one is c
+        const long long lo = (long long)t * G, hi = lo + G - 1;
+        const int w_first = (int)(((lo + 1) * nwg - 1) / sk_total), w_last = (int)(((hi + 1) * nwg - 1) / sk_total);
+        const int c = wg - w_first, ncontrib = w_last - w_first + 1;
+        constexpr int SLOT = BM * BN;                    // floats per slot; lane-major: [wave][a][b][lane] x f32x4
+        f32x4* slot = reinterpret_cast<f32x4*>(sk_ws + ((long long)t * SK_MAXC + c) * SLOT);
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) slot[((wave * NT + a) * 4 + b) * 64 + lane] = acc[a][b];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the release follows
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the write-back has completed
+            const int old = __hip_atomic_fetch_add(&sk_cnt[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == ncontrib - 1;
+            if (last) {
+                __hip_atomic_store(&sk_cnt[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // this CU's L1 forgets the other slots
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            sk_last = last;
+        }
+        __syncthreads();
+        if (!sk_last) continue;                          // somebody else finishes the tile (wave-uniform: LDS word)
+        for (int cc = 0; cc < ncontrib; ++cc) {
+            if (cc == c) continue;
+            const f32x4* other = reinterpret_cast<const f32x4*>(sk_ws + ((long long)t * SK_MAXC + cc) * SLOT);
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += other[((wave * NT + a) * 4 + b) * 64 + lane];
+        }
+    }
+
     // ---- epilogue (same contract as gemm.hip) through a per-wave LDS slab: 64 rows x 48 columns
     float* __restrict__ C = g.C ? g.C + zo * g.sCo + zi * g.sCi : nullptr;
     uint16_t* __restrict__ Chi = g.Chi ? g.Chi + zo * g.sCo + zi * g.sCi : nullptr;
@@ -324,6 +395,36 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                 }
         }
     }
+    if (!sk_total) break;
+    bar();            // the slabs overlay the stages: every wave has read its slab before the next item's LDS-DMA lands
+  }
+}
+
+// MEASURED (round 3, beside the sampler, 224 CUs, M = 8000, bf16x3; scripts/bench_enc_gemm.py): stream-K LOSES on every
+// encoder projection - qkv 121 -> 147 us, out 49 -> 71 us, ffn2 124 -> 182 us.  With 189 tiles on 224 CUs nearly every
+// workgroup's share is a tile tail plus a tile head, i.e. two shared tiles: two 128 KB partials stored at the CU's ~14
+// B/clk store rate (~5 us each), two agent-scope releases (each writes back its XCD's whole L2, other workgroups' output
+// tiles included) and one or two partials read back cost 25-55 us against the 16 % (20 us) of a tile the equal shares save.
+// It is therefore OFF unless AVI_GEMM_STREAMK asks for it (1: by the plan below, 2: whenever legal); the path stays
+// tested (tests/test_gpu_ops.py::test_stream_k_gemm).  What would pay is a fix-up that does not go through HBM-side
+// stores (none exists between CUs on this chip) or problems with K >> 3072.
+// Plan (mode 1): shares of at least 4 K groups (12 K tiles), at most SK_MAXC contributors per tile, a last round filled
+// to less than 90 %.  Returns the number of workgroups to launch (0 = plain data-parallel launch).
+template <int NT>
+int stream_k_plan(const AviGemm& g, int tiles, int nk) {
+    const char* e_ = getenv("AVI_GEMM_STREAMK");                // 0 off (default), 1 by the plan below, 2 whenever legal
+    const int mode = e_ ? atoi(e_) : 0;
+    if (!mode || !g.sk_ws || g.batch != 1 || g.cus <= 0 || g.cus > 256) return 0;
+    const int G = nk / 3, cus = g.cus;
+    const long long total = (long long)tiles * G;
+    const long long need = (long long)tiles * SK_MAXC * BM * Geo<NT>::BN + tiles + 64;   // floats: slots + counters
+    if (g.sk_ws_floats < need) return 0;
+    const long long share = total / cus;                      // K groups per workgroup (floor)
+    if (share < 4 || (long long)(SK_MAXC - 2) * share < G) return 0;      // a tile spans <= G / share + 2 shares
+    const int rounds = (tiles + cus - 1) / cus;
+    const double fill = (double)tiles / ((double)rounds * cus);
+    if (mode != 2 && fill > 0.90) return 0;
+    return cus;
 }
 
 template <int NS, int NT, bool F16 = false>
@@ -332,8 +433,17 @@ int launch(const AviGemm& g, hipStream_t s) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp192_kernel<NS, NT, F16>), SMEM_BYTES);
+    const int nk = g.K / (NS == 2 ? 32 : 64);
+    const int sk_wgs = stream_k_plan<NT>(g, tilesM * tilesN, nk);
+    if (sk_wgs) {
+        float* ws = g.sk_ws;
+        int* cnt = reinterpret_cast<int*>(ws + (long long)tilesM * tilesN * SK_MAXC * BM * BN);
+        hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT, F16>), dim3(sk_wgs, 1), dim3(NTHR), SMEM_BYTES, s, g, tilesM, tilesN,
+                           tilesM * tilesN * (nk / 3), ws, cnt);
+        return avi_launch_status();
+    }
     hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT, F16>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
-                       tilesN);
+                       tilesN, 0, nullptr, nullptr);
     return avi_launch_status();
 }
 

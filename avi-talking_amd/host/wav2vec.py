@@ -49,6 +49,10 @@ class Wav2Vec2Model:
         self.use_planes_tf = os.environ.get("AVI_W2V_TF_PLANES", "1") == "1"
         # positional conv: its own kernel (AVI_W2V_POSCONV=gemm: the overlapping-row GEMM per (clip, group) on gemm.hip)
         self.posconv_kernel = os.environ.get("AVI_W2V_POSCONV", "kernel") != "gemm"
+        # stream-K for the 128-row projections: measured slower than the data-parallel launch at these sizes (csrc/
+        # gemm_pp192.hip), so the 400 MB workspace is only allocated on request (AVI_W2V_STREAMK=1 + AVI_GEMM_STREAMK=1/2)
+        self.stream_k = os.environ.get("AVI_W2V_STREAMK", "0") == "1"
+        self._sk_ws = None
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -151,15 +155,23 @@ class Wav2Vec2Model:
         # LayerNorm outputs feed a big GEMM (qkv / ffn1) AND the residual: emitted as split planes + fp32
         PA, PF = self.plan.attn, self.plan.ffn               # every producer writes the format its consumer reads
         FA, FF = ops.plane_fmt(PA), ops.plane_fmt(PF)
+        # stream-K workspace of the 128-row GEMMs (csrc/gemm_pp192.hip): only when the caller says how many CUs are free -
+        # M = 8000 on the 224 CUs beside the sampler leaves 16 % of the last round of qkv / out / ffn2 idle otherwise
+        ws = None
+        if cus and self.stream_k:
+            M = h.shape[0] * h.shape[1]
+            if self._sk_ws is None or self._sk_ws[0] != M:
+                self._sk_ws = (M, ops.stream_k_workspace(M, 3 * HIDDEN, self.device))
+            ws = self._sk_ws[1]
         h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=FA)
         d = HIDDEN // HEADS
         for ly in self.layers:   # every projection on the ping-pong GEMMs, every activation split once
-            qkv = ops.linear_planes(hp_, ly.qkv, prec=PA, cus=cus)                    # (B,T,2304) fp32
+            qkv = ops.linear_planes(hp_, ly.qkv, prec=PA, cus=cus, sk_ws=ws)          # (B,T,2304) fp32
             att = ops.attention_d64_planes(qkv, HEADS, d ** -0.5, fmt=FA)            # planes
-            h = ops.linear_planes(att, ly.out, residual=h, prec=PA, cus=cus)
+            h = ops.linear_planes(att, ly.out, residual=h, prec=PA, cus=cus, sk_ws=ws)
             h, hp_ = ops.layernorm_planes(h, *ly.ln1, out=h, fmt=FF)
             f = ops.linear_planes(hp_, ly.ff1, act=ops.ACT_GELU, prec=PF, out_planes=True, cus=cus)
-            h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF, cus=cus)
+            h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF, cus=cus, sk_ws=ws)
             h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=FA)
         return h
 

@@ -34,6 +34,7 @@ class AviGemm(C.Structure):
         ("Ahi", _vp), ("Alo", _vp), ("Chi", _vp), ("Clo", _vp),
         ("ldw", _i), ("cus", _i),
         ("C16", _vp),
+        ("sk_ws", _vp), ("sk_ws_floats", _ll),
     ]
 
 

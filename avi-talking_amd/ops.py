@@ -105,7 +105,7 @@ class PackedWeight:
 
 def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0, scale=None, shift=None, act=ACT_NONE,
              prec=PREC_BF16X3, batch=1, z_inner=1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sB=(0, 0), sR=(0, 0),
-             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0, cus=0, C16=0):
+             Ahi=0, Alo=0, Chi=0, Clo=0, ldw=0, cus=0, C16=0, sk_ws=None):
     """Direct access to ``avi_gemm``; pointers are ints (tensor.data_ptr() + byte offsets).  ``cus``: compute units the
     launch can count on (0 = all 256): the sampling pipeline passes what the sampler's resident workgroups leave, so that
     the plane-operand kernels pick tile shapes that fill whole rounds of the CUs that are actually free (AviGemm.cus)."""
@@ -113,6 +113,8 @@ def gemm_raw(*, A=0, lda, Whi, Wlo, C_=0, ldc, M, N, K, bias=None, R=None, ldr=0
     g.ldw = ldw
     g.cus = cus
     g.C16 = C16 or None
+    if sk_ws is not None:           # stream-K workspace (fp32 tensor, zero-filled once by its owner): AviGemm.sk_ws
+        g.sk_ws, g.sk_ws_floats = sk_ws.data_ptr(), sk_ws.numel()
     g.A, g.lda, g.sAo, g.sAi = A or None, lda, sA[0], sA[1]
     g.Ahi, g.Alo, g.Chi, g.Clo = Ahi or None, Alo or None, Chi or None, Clo or None
     g.Whi, g.Wlo, g.sWo, g.sWi = Whi, Wlo, sW[0], sW[1]
@@ -435,7 +437,14 @@ def conv1d_cl_planes(xp, pw, ksize, stride, act=ACT_NONE, prec=PREC_BF16X3, out_
     return out
 
 
-def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None, out_planes=False, cus=0):
+def stream_k_workspace(M, N, device):
+    """Zero-filled workspace that lets the 128-row plane-operand GEMM cut an (M x N) problem into equal K shares when its
+    tiles do not fill the last round of the CUs it may count on (AviGemm.sk_ws; one launch at a time uses it)."""
+    tiles = -(-M // 128) * -(-N // 192)            # 128 x 192 tiles are the smaller shape: more tiles, smaller slots
+    return torch.zeros(tiles * 4 * 128 * 256 + tiles + 64, dtype=torch.float32, device=device)
+
+
+def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=None, out_planes=False, cus=0, sk_ws=None):
     """out[..., N] = act(x @ W^T + b) + residual with x given as split planes; the result is fp32, or split planes
     too (``out_planes=True``: a ``Planes`` for the next GEMM)."""
     K = xp.shape[-1]
@@ -458,7 +467,7 @@ def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=Non
     whi, wlo = pw.planes_for(prec)
     gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=whi, Wlo=wlo,
              ldc=pw.N, M=M, N=pw.N, K=K, bias=L.ptr(pw.bias), R=L.ptr(residual), ldr=pw.N, act=act, prec=prec, cus=cus,
-             **c_args)
+             sk_ws=sk_ws, **c_args)
     return out
 
 

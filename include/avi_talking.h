@@ -91,6 +91,13 @@ typedef struct AviGemm {
      * counted in elements; C may then be NULL.  The EMOTE head's last layer writes its coefficients this way for long-form
      * batches (BASELINE.json configs[4]: "fp16 coeffs"): half the bytes, |rounding| <= 2^-11 |value|. */
     uint16_t* C16;
+    /* Optional STREAM-K workspace for the 128-row plane-operand kernel (batch 1, cus > 0): device memory of sk_ws_floats
+     * floats, zero-filled ONCE by the caller (the kernel leaves its tile counters at zero), used by one launch at a time
+     * (stream order).  With it, a problem whose tiles do not fill the last round of `cus` workgroups is cut along K into
+     * `cus` equal shares; tiles shared by several workgroups are finished by the contributor that arrives last (csrc/
+     * gemm_pp192.hip).  Size: tiles(128 x 256) * 4 * 128 * 256 + tiles + 64 floats (74 MB at M = 8000, N = 768).  NULL = off. */
+    float* sk_ws;
+    long long sk_ws_floats;
 } AviGemm;
 int avi_gemm(const AviGemm* g, void* stream);
 

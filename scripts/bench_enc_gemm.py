@@ -34,7 +34,8 @@ for name, N, K, act, resid in shapes:
     xp.hi.copy_(hi.view(torch.int16)); xp.lo.copy_((x - hi.float()).to(dt).view(torch.int16))
     pw = ops.PackedWeight(torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev))
     R = torch.randn(M, N, device=dev) if resid else None
-    run = lambda: ops.linear_planes(xp, pw, act=act, residual=R, prec=prec, out_planes=not resid, cus=cus)
+    ws = ops.stream_k_workspace(M, N, dev) if os.environ.get("SK", "0") == "1" else None
+    run = lambda: ops.linear_planes(xp, pw, act=act, residual=R, prec=prec, out_planes=not resid, cus=cus, sk_ws=ws)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -51,5 +52,5 @@ for name, N, K, act, resid in shapes:
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     us = ts[len(ts) // 2] * 1e3
     fl = 2.0 * M * N * K
-    print(f"{name:8s} N={N:5d} K={K:5d} cus={cus} kernel={os.environ.get('AVI_GEMM_KERNEL','auto')}: {us:7.1f} us  "
+    print(f"{name:8s} N={N:5d} K={K:5d} cus={cus} kernel={os.environ.get('AVI_GEMM_KERNEL','auto')} sk={os.environ.get('SK','0')}: {us:7.1f} us  "
           f"{fl/us/1e6:6.1f} TFLOP/s algorithmic", flush=True)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header(lib):
     import ctypes as C
     # AviGemm: 21 pointer/long long fields of 8 bytes + 7 ints, padded to 8
-    assert C.sizeof(lib.AviGemm) == 21 * 8 + 8 * 4 + 4 * 8 + 8 + 8      # + ldw, cus (two ints) + C16
+    assert C.sizeof(lib.AviGemm) == 21 * 8 + 8 * 4 + 4 * 8 + 8 + 8 + 16  # + ldw, cus (two ints) + C16 + sk_ws, sk_ws_floats
     assert C.sizeof(lib.AviPriorLayer) == 8 * 8
     assert C.sizeof(lib.AviPriorWeights) == 8 + 13 * 8 + 8 * 64 + 5 * 8
     assert C.sizeof(lib.AviFaceformerWeights) == 16 + 23 * 8

@@ -416,3 +416,46 @@ def test_transpose_jobs_and_table(gpu):
         assert (v[:Cc] - x.t()).abs().max().item() < 2e-5 * x.abs().max().item()
         assert torch.equal(hi[:Cc].view(torch.bfloat16), x.t().contiguous().to(torch.bfloat16))
         assert not v[Cc:].any()
+
+
+@pytest.mark.parametrize("M,N,K,budget,prec", [(8000, 768, 768, 224, 3), (8000, 2304, 768, 224, 3), (8000, 768, 3072, 224, 3),
+                                               (8000, 768, 3072, 224, 2), (8000, 768, 3072, 256, 3), (4000, 768, 768, 100, 3),
+                                               (1000, 768, 1536, 7, 3), (640, 2304, 768, 48, 1)])
+def test_stream_k_gemm(gpu, monkeypatch, M, N, K, budget, prec):
+    """Stream-K on the 128-row plane-operand GEMM (AviGemm.sk_ws, csrc/gemm_pp192.hip): the K loops of all tiles cut into
+    `cus` equal shares, shared tiles finished by the last contributor.  Against float64 and against the data-parallel launch
+    of the same kernel (same tile shape, no workspace); repeated launches reuse the workspace (counters return to zero);
+    fp32 and plane outputs, bias, GELU and residual in the epilogue.  (The path is opt-in: at the encoder's sizes it measured
+    slower than the data-parallel launch, csrc/gemm_pp192.hip.)"""
+    from avi_talking_amd import ops
+    monkeypatch.setenv("AVI_GEMM_STREAMK", "2")          # force: also where the plan would not bother
+    monkeypatch.setenv("AVI_GEMM_KERNEL", "6")           # 128 x 256 tiles
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    fmt = ops.plane_fmt(prec)
+    xp = ops.Planes((M, K), gpu, fmt)
+    dt = torch.float16 if fmt == ops.PLANES_F16 else torch.bfloat16
+    hi = x.to(dt)
+    xp.hi.copy_(hi.view(torch.int16).to(gpu))
+    xp.lo.copy_((x - hi.float()).to(dt).view(torch.int16).to(gpu))
+    ws = ops.stream_k_workspace(M, N, gpu)
+    rg = r.to(gpu)
+    plain = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=rg, prec=prec, cus=budget)
+    for rep in range(3):
+        out = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=rg, prec=prec, cus=budget, sk_ws=ws)
+        torch.cuda.synchronize()
+        err = (out.cpu().double() - ref).abs().max().item()
+        tol = {3: 3e-5, 2: 2e-3, 1: 5e-2}[prec] * max(1.0, (K / 64) ** 0.5)
+        assert err < tol, (rep, err)
+        # a shared tile is summed in another order than a tile computed by one workgroup: a few fp32 ulps
+        assert (out - plain).abs().max().item() < 2e-5 * max(1.0, (K / 64) ** 0.5)
+    # the counters sit behind the slots of whichever tile shape ran (128 x 256 or 128 x 192): all back at zero, and the
+    # slots were written (the launch really took the stream-K path)
+    for bn in (256, 192):
+        tiles = -(-M // 128) * -(-N // bn)
+        cnt = ws[tiles * 4 * 128 * bn: tiles * 4 * 128 * bn + tiles].view(torch.int32)
+        assert int(cnt.abs().sum()) == 0
+    assert float(ws.abs().sum()) > 0
+    outp = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=rg, prec=prec, out_planes=True, cus=budget, sk_ws=ws)
+    assert (outp.float() - out).abs().max().item() < 1e-4 * max(1.0, out.abs().max().item())
