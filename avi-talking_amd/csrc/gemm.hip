@@ -283,12 +283,8 @@ static double tile_score(const AviGemm& g, int bm, int bn, double eff) {
 }
 
 static int gemm_kernel_choice() {   // AVI_GEMM_KERNEL = 2 / 4 / 5 / 6: A/B switches of the plane-operand dispatch below
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("AVI_GEMM_KERNEL");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
+    const char* e = getenv("AVI_GEMM_KERNEL");   // read per launch (tests switch it inside one process)
+    return e ? atoi(e) : 0;
 }
 
 extern "C" int avi_gemm(const AviGemm* gp, void* stream) {

@@ -420,7 +420,7 @@ def test_transpose_jobs_and_table(gpu):
 
 @pytest.mark.parametrize("M,N,K,budget,prec", [(8000, 768, 768, 224, 3), (8000, 2304, 768, 224, 3), (8000, 768, 3072, 224, 3),
                                                (8000, 768, 3072, 224, 2), (8000, 768, 3072, 256, 3), (4000, 768, 768, 100, 3),
-                                               (1000, 768, 1536, 7, 3), (640, 2304, 768, 48, 1)])
+                                               (1000, 768, 1536, 7, 3), (640, 2304, 768, 24, 1)])
 def test_stream_k_gemm(gpu, monkeypatch, M, N, K, budget, prec):
     """Stream-K on the 128-row plane-operand GEMM (AviGemm.sk_ws, csrc/gemm_pp192.hip): the K loops of all tiles cut into
     `cus` equal shares, shared tiles finished by the last contributor.  Against float64 and against the data-parallel launch
