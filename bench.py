@@ -144,11 +144,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # 0.6 s of timed region: the clock settles within the first passes
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2", "mixed", "mixed_ffn"], default="bf16x3",
-                    help="bf16x3 = 3-term split bf16 MFMA (2e-5 on the coefficients; default and headline); mixed = conv layers "
-                         "1-6 in 2-term fp16, transformer projections 3-term bf16; mixed_ffn = conv and ffn 2-term, q/k/v/out "
-                         "3-term; f16x2 = every plane-operand GEMM and the sampler 2-term fp16 (6e-4, inside the 1e-3 gate); "
-                         "bf16 = 1 term (fails the gate)")
+    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2", "mixed", "mixed_ffn"], default="mixed",
+                    help="mixed (default, headline) = conv layers 1-6 (half of the FLOPs) in 2-term fp16 (fp16 hi/lo activation "
+                         "planes x one fp16 weight plane), transformer projections, heads and sampler in 3-term bf16: 2.5e-4 max-abs "
+                         "on the coefficients vs the oracle on every tested config, gated at 3e-4 (north_star: 1e-3; the reference "
+                         "itself runs fp16 autocast); bf16x3 = 3-term split bf16 everywhere (2e-5); mixed_ffn = conv and ffn 2-term "
+                         "(3.5-4.7e-4); f16x2 = every plane-operand GEMM and the sampler 2-term fp16 (6-8e-4); bf16 = 1 term (fails "
+                         "the gate).  Every mode is timed by the precision_modes leg")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="replay the pass as ONE graph, passes strictly one after the other (default: two graphs on two "
@@ -258,7 +260,10 @@ def main():
                              "work, results bit-identical to the one-graph replay",
                    "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
-        "max_abs_coeff_err_vs_oracle": "see tests/test_gpu_emote.py: 2e-5 (bf16x3)",
+        "max_abs_coeff_err_vs_oracle": {"mixed": "1.9e-4 - 2.5e-4 (tests/test_gpu_mixed_prec.py: configs[0], configs[1] sub-batch, "
+                                                 "T = 1500; gate 3e-4)", "bf16x3": "2e-5 (tests/test_gpu_emote.py)",
+                                        "north_star_gate": 1e-3}.get(args.prec, "see precision_modes") if args.prec in ("mixed", "bf16x3")
+        else "see precision_modes",
         "roofline": None, "cpu_baseline": None, "precision_modes": None, "train": None, "faceformer": None, "longform": None, "flame": None,
         "clip_text": None,
     }
@@ -559,6 +564,16 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         srec.append((e0, e1))
         return out
 
+    arec = []
+    orig_aligner = prior.voxel2clip
+
+    def timed_aligner(*a, **kw):                     # the aligner opens the sampler's branch (text feature -> text_embed)
+        s, e0, e1 = ev_pair()
+        out = orig_aligner(*a, **kw)
+        e1.record(s)
+        arec.append((e0, e1))
+        return out
+
     marks = []
     try:
         wrap("gemm_raw", gemm_work)
@@ -568,6 +583,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         wrap("layernorm_planes", ln_work)
         wrap("interp_layernorm", interp_work)
         prior.p_sample_loop = timed_sample
+        prior.voxel2clip = timed_aligner
         for _ in range(reps + 1):      # pass 0 lets the host run ahead of the device and is dropped
             marks.append(len(rec))
             pipe.run(pcm, voxel, noise)
@@ -576,6 +592,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         for name, fn in saved.items():
             setattr(ops, name, fn)
         prior.p_sample_loop = orig_sample
+        prior.voxel2clip = orig_aligner
     marks.append(len(rec))
     # every pass issues the same launches in the same order: a launch slot's duration is the MINIMUM over the kept
     # passes, so a host hiccup between recording e0 and enqueueing the kernel (eager mode) cannot inflate a family
@@ -664,6 +681,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         plane_bytes = sum(t.numel() * t.element_size() for t in prior.net._packs)
         T = prior.noise_scheduler.num_timesteps
         nbytes = plane_bytes * T * groups
+        ams = min(a.elapsed_time(b) for a, b in arec[1:]) if len(arec) > 1 else 0.0
         entries.append({
             "bound": "hbm", "bound_detail": "weights re-streamed L2 -> CU every DDPM step (per-CU ingest, served by L2 / "
                                             "Infinity Cache: neither the HBM nor the MFMA roof); latency-bound chain of "
@@ -671,6 +689,9 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             "kernel": f"prior sampler ({T}-step DDPM in one launch, {groups} sample groups on {cus} CUs, side stream)",
             "achieved": round(nbytes / sms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(nbytes / sms / 1e6 / 8000.0, 4), "per_cu_gbps": round(nbytes / cus / sms / 1e6, 1),
+            # what actually bounds it: a CU takes in 66-73 GB/s from its XCD's L2 (MI355X_MICROARCH.md, gather rates)
+            "per_cu_ingest_ceiling_gbps": 70.0, "frac_of_ingest_ceiling": round(nbytes / cus / sms / 1e6 / 70.0, 3),
+            "aligner_ms_in_front_of_it": round(ams, 3), "branch_ms": round(sms + ams, 3),
             "launches_per_step": 1, "avg_launch_us": round(sms * 1e3, 1), "ms_per_step": round(sms, 3),
             "frac_of_step": round(sms / step_ms, 3), "algorithmic_bytes_per_launch": nbytes,
             "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
@@ -681,9 +702,10 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
     smp = [e for e in entries if e["kernel"].startswith("prior sampler")]
     entries = sorted((e for e in entries if e not in smp), key=lambda e: -e["ms_per_step"])
     if smp:
-        bounds = smp[0]["ms_per_step"] >= 0.95 * step_ms
-        smp[0]["role"] = ("bounds the step" if bounds else
-                          f"beside the audio branch with {step_ms - smp[0]['ms_per_step']:.1f} ms of slack (eager, instrumented pass)")
+        # its branch = the aligner in front of it + the launch itself; the rest of a pass is hand-over between graphs
+        bounds = smp[0]["branch_ms"] >= 0.95 * step_ms
+        smp[0]["role"] = ("its branch (aligner + sampler) bounds the step" if bounds else
+                          f"beside the audio branch with {step_ms - smp[0]['branch_ms']:.1f} ms of slack (eager, instrumented pass)")
         entries.insert(0 if bounds else 1, smp[0])
     out = entries[0]
     out["others"] = entries[1:]
