@@ -270,12 +270,22 @@ class InstructDiffusionPrior:
         # 1..5 = matrix-core kernel (prior_mfma.hip).  AVI_PRIOR_SPG overrides (tuning knob).
         import os
         self.samples_per_group = int(os.environ.get("AVI_PRIOR_SPG", "1"))
+        # PAIRED sampler (csrc/prior_pair.hip): two samples on two CUs, each streaming half of every matrix; needs the
+        # default plane formats (feed-forward fp16, attention bf16 hi / lo).  AVI_PRIOR_PAIR=0/1 overrides.
+        self.paired = os.environ.get("AVI_PRIOR_PAIR", "0") == "1" and net.ff_fp16 and not net.attn_fp16
+        self._pair_ws = {}
 
     @classmethod
     def from_state_dict(cls, state_dict, device="cuda", prec=ops.PREC_BF16X3, timesteps=100, attn_fp16=None):
         net = VersatileDiffusionPriorNetwork(state_dict, device=device, timesteps=timesteps, attn_fp16=attn_fp16)
         v2c = BrainNetwork(state_dict, device=device, prec=prec)
         return cls(net, voxel2clip=v2c, timesteps=timesteps, device=device)
+
+    def pair_status(self):
+        """After a synchronisation: raises if a paired-sampler launch saw a partner that never answered (bounded spin)."""
+        for B, ws in self._pair_ws.items():
+            if int(ws[1].item()) != 0:
+                raise RuntimeError(f"paired sampler (B={B}): exchange timed out, results are invalid")
 
     def time_table(self):
         """(T, 128) time embeddings of every timestep (models/diffusion_prior.py:188-191,284), built on first use."""
@@ -326,6 +336,15 @@ class InstructDiffusionPrior:
             L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
                                               1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
                                               L.stream_ptr()), "avi_prior_sample")
+        elif self.paired and samples_per_group is None:
+            ws = self._pair_ws.get(B)
+            if ws is None:        # zero-filled once, then owned by the library (launch epoch + exchange slots)
+                nbytes = L.load().avi_prior_pair_workspace_bytes(B)
+                ws = self._pair_ws[B] = torch.zeros(nbytes // 8, dtype=torch.int64, device=self.device)
+            L.check(L.load().avi_prior_sample_paired(C.byref(self.net.cw), C.byref(self.net.planes), te.data_ptr(),
+                                                     noise.data_ptr(), B, 1.0 / self.image_embed_scale, out.data_ptr(),
+                                                     self.time_table().data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                    "avi_prior_sample_paired")
         else:            # up to 5 samples per workgroup on the matrix cores (prior_mfma.hip), ONE launch: the time
             spg = min(spg, B)      # embeddings of all steps are a constant of the weights, built once (time_table)
             L.check(L.load().avi_prior_sample_batched_tab(C.byref(self.net.cw), C.byref(self.net.planes),

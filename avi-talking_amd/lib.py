@@ -148,6 +148,8 @@ SIGNATURES = {
     "avi_prior_sample_batched": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "avi_prior_sample_batched_tab": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "avi_prior_time_table": [_vp, _vp, _vp],
+    "avi_prior_sample_paired": [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp],
+    "avi_prior_pair_workspace_bytes": [_i],                  # returns long long (RESTYPES below)
     "avi_faceformer_decode": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "avi_faceformer_decode_chunked": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "avi_faceformer_decode_chunked_f16": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
@@ -182,6 +184,7 @@ SIGNATURES = {
     "avi_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp],
 }
 
+RESTYPES = {"avi_prior_pair_workspace_bytes": _ll}          # everything else returns an int status
 _lib = None
 
 
@@ -204,7 +207,7 @@ def load():
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = RESTYPES.get(name, _i)
         _lib = lib
     return _lib
 

@@ -281,6 +281,17 @@ int avi_prior_sample_batched_tab(const AviPriorWeights* w, const AviPriorPlanes*
                                  const float* noise, int B, int samples_per_group, float inv_scale, float* out,
                                  const float* temb_table, void* stream);
 
+/* PAIRED sampler (csrc/prior_pair.hip): two samples share two workgroups on two CUs and each streams HALF of every layer's
+ * matrices (q heads / feed-forward halves; the partial sums of to_out and ff2 cross between the partners as tagged 8-byte
+ * granules), because the loop above is bound by what ONE CU can take in from L2.  Same contract as
+ * avi_prior_sample_batched_tab; plane formats: feed-forward matrices one fp16 plane, attention matrices bf16 hi / lo (the
+ * default).  workspace: avi_prior_pair_workspace_bytes(B) bytes, zero-filled ONCE by the caller, then owned by the library
+ * (launch epoch, exchange slots); one launch at a time (stream order).  After the launch has completed, workspace word 1
+ * (u64) != 0 means a partner never answered within the bounded spin: the result is invalid. */
+long long avi_prior_pair_workspace_bytes(int B);
+int avi_prior_sample_paired(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed, const float* noise,
+                            int B, float inv_scale, float* out, const float* temb_table, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * FaceFormer-style autoregressive decoder.  Replaces the loop of Faceformer.predict
  * (models/faceformer.py:710-729; teacher-free branch of forward_switch_frame :392-409) over

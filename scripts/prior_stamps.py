@@ -14,8 +14,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 c = out.view(B, 128)[0, :12].double()
 names = ["A pre-LN", "B qkv run", "C attention", "D out run", "E LN x2", "F ff1 run", "G swiglu", "H ff2 run",
-         "final proj", "step setup+update"]
-tot = c[:10].sum().item()
-for n, v in zip(names, c[:10].tolist()):
+         "final proj", "step setup+update", "exchange 1 (+ prefetch ff1)", "exchange 2 (+ prefetch qkv)"]
+tot = c[:12].sum().item()
+for n, v in zip(names, c[:12].tolist()):
     print(f"{n:18s} {v/600:8.0f} cycles per layer-step  {100*v/tot:5.1f} %")
 print(f"total {tot/100:.0f} cycles per DDPM step")

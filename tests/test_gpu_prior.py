@@ -101,3 +101,60 @@ def test_sampler_all_fp16_planes_opt_in(gpu):
     err0 = (dflt.p_sample_loop((B, 1, 128), text_cond={"text_embed": te.to(gpu)}, noise=noise.to(gpu)).cpu() - ref).abs().max().item()
     print(f"all-fp16 sampler: style err {err:.2e} (default variant {err0:.2e})")
     assert err < 1e-3 and err0 < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 32])
+def test_paired_sampler_matches_oracle_and_unpaired_kernel(gpu, monkeypatch, B):
+    """csrc/prior_pair.hip: two samples on two workgroups, each streaming half of every matrix, partial sums of to_out / ff2
+    exchanged as tagged granules.  Against the CPU oracle (1e-3 gate on the style, as for the unpaired kernel) and against the
+    unpaired matrix-core kernel (same arithmetic up to the order of two fp32 partial sums); odd batch sizes leave a pair with
+    one sample; three launches in a row reuse the workspace (the launch epoch separates their granules)."""
+    from avi_talking_amd.weights import make_prior_weights
+    from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior
+    from oracle import prior as OP
+    wp = make_prior_weights(3)
+    g = torch.Generator().manual_seed(40 + B)
+    te, noise = torch.randn(B, 1, 128, generator=g), torch.randn(101, B, 1, 128, generator=g)
+    monkeypatch.setenv("AVI_PRIOR_PAIR", "0")
+    base = InstructDiffusionPrior.from_state_dict(wp, device=gpu)
+    ref_gpu = base.p_sample_loop((B, 1, 128), text_cond={"text_embed": te.to(gpu)}, noise=noise.to(gpu)).cpu()
+    monkeypatch.setenv("AVI_PRIOR_PAIR", "1")
+    pr = InstructDiffusionPrior.from_state_dict(wp, device=gpu)
+    assert pr.paired and not base.paired
+    outs = []
+    for _ in range(3):
+        outs.append(pr.p_sample_loop((B, 1, 128), text_cond={"text_embed": te.to(gpu)}, noise=noise.to(gpu)).cpu())
+        torch.cuda.synchronize()
+        pr.pair_status()
+    assert int(pr._pair_ws[B][0].item()) == 3                       # three launches, three epochs
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    d_gpu = (outs[0] - ref_gpu).abs().max().item()
+    nb = min(B, 4)
+    ref = OP.p_sample_loop(wp, te[:nb], noise[:, :nb])
+    d_or = (outs[0][:nb] - ref).abs().max().item()
+    print(f"paired sampler B={B}: vs unpaired kernel {d_gpu:.2e}, vs oracle {d_or:.2e}")
+    assert d_gpu < 2e-4 and d_or < 1e-3
+
+
+def test_paired_sampler_in_a_graph(gpu, monkeypatch):
+    """The paired launch + its epoch kernel captured in a hipGraph: replays give the eager result (the epoch advances on the
+    device, so every replay uses fresh tags)."""
+    from avi_talking_amd.weights import make_prior_weights
+    from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior
+    monkeypatch.setenv("AVI_PRIOR_PAIR", "1")
+    pr = InstructDiffusionPrior.from_state_dict(make_prior_weights(3), device=gpu)
+    B = 6
+    g = torch.Generator().manual_seed(3)
+    te, noise = torch.randn(B, 1, 128, generator=g).to(gpu), torch.randn(101, B, 1, 128, generator=g).to(gpu)
+    pr.time_table()
+    eager = pr.p_sample_loop((B, 1, 128), text_cond={"text_embed": te}, noise=noise).clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pr.p_sample_loop((B, 1, 128), text_cond={"text_embed": te}, noise=noise)
+    for _ in range(4):
+        graph.replay()
+    torch.cuda.synchronize()
+    pr.pair_status()
+    assert torch.equal(out, eager)
+    assert int(pr._pair_ws[B][0].item()) == 5
