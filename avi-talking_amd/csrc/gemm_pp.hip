@@ -33,6 +33,8 @@
 //     the vmcnt arithmetic uniform (3 % extra L2 reads at K = 1536).
 //   * LDS image and fragment addressing as in gemm_dma.hip: lane-linear LDS-DMA with the bank swizzle applied on the
 //     SOURCE address (chunk c of row R sits at c ^ (R & 7)); fragments by ds_read_b128, conflict-free.
+#include <cstdlib>
+
 #include "common.h"
 #include "gelu_table.h"
 
@@ -47,7 +49,8 @@ constexpr int EP_STRIDE = 272;                 // epilogue slab: 64 fp32 + 16 B 
 constexpr int EP_SLAB = 64 * EP_STRIDE;        // per wave
 constexpr int WORK_BYTES = 8 * EP_SLAB > 2 * STAGE_BYTES ? 8 * EP_SLAB : 2 * STAGE_BYTES;   // 136 KiB
 constexpr int TAB_BYTES = 2048;                // GELU table (gelu_table.h), behind the stages / slabs for the whole kernel
-constexpr int SMEM_BYTES = WORK_BYTES + TAB_BYTES;
+constexpr int DUMMY_BYTES = 8 * 2 * 256;       // landing pad of the WS mode's dummy pieces (one 4-byte load per lane)
+constexpr int SMEM_BYTES = WORK_BYTES + TAB_BYTES + DUMMY_BYTES;
 constexpr int KX0 = 0, KX1 = 1, KW0 = 2, KW1 = 3;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -64,8 +67,20 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // F16 (with NS = 2): the opt-in 2-term fp16 mode AVI_PREC_F16X2 - activation planes are fp16 hi/lo, the weight is ONE fp16
 // plane (the "lo" half of a staged weight row is a second copy nobody multiplies), y = w.xh + w.xl: two MFMAs per
 // product instead of three; plane outputs are split into fp16 hi/lo.
-template <int NS, bool F16 = false>
+// WS (F16 only, K tiles in fours): WEIGHT SUPER-TILES.  In F16 mode the "lo" half of a staged weight row used to be a second
+// copy of the same 64 bytes; a 256 x 256 tile then stages 64 KB per 32-deep K tile = 2 430 cycles at the CU's 27 B/clk against
+// 2 048 cycles of MFMAs (two per product): the 2-term tile is INGEST-bound, which is why it gained only 17-21 % from a third
+// fewer MFMAs.  With WS the lo half holds the NEXT K tile's 64 bytes: weights are staged for even K tiles only (into the
+// W areas of stage (T / 2) & 1), an odd K tile reads its fragments from the lo position of the previous tile's rows, and the
+// issue slots that used to stage an odd tile's weights issue DUMMY pieces (4 bytes per lane into a landing pad) so that
+// every wave still issues two pieces per phase and the counted `vmcnt(6)` waits keep their meaning unchanged.  Hazards:
+//   WAR  the W areas of stage (j + 1) & 1 were last read by super-tile j - 1 (its odd tile: W0 in P1, W1 in P2); super-tile
+//        j + 1 is issued into them in P4 of tile 2j (W0) and P1 of tile 2j + 1 (W1): at least six phases later;
+//   RAW  the real issues sit in exactly the slots, 5 phases ahead of the first read, that staged the even tiles before;
+//        the odd tile reads the same rows 4 phases later still.
+template <int NS, bool F16 = false, bool WS = false>
 __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+    static_assert(!WS || (F16 && NS == 2), "weight super-tiles exist in the 2-term fp16 mode only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
         for (int i = 0; i < 2; ++i) {
             const int R = (wave + 8 * i) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (R & 7);
-            const int off = NS == 2 ? (c & 3) * 16 : c * 16;
+            const int off = (NS == 2 && !(WS && kind >= 2)) ? (c & 3) * 16 : c * 16;   // WS: 128 contiguous bytes of the fp16 row
             if (kind < 2) {   // activation rows: wave-row wr' = R / 64 owns rows wr' * 128 + h * 64 + R % 64
                 int m = m0 + (R >> 6) * 128 + kind * 64 + (R & 63);
                 m = m < g.M ? m : g.M - 1;
@@ -113,9 +128,15 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     const int nk = g.K / (NS == 2 ? 32 : 64);   // even, >= 2 (checked by the launcher)
 
     const bool diag_noload = g.prec & 0x100, diag_nomfma = g.prec & 0x200;   // timing diagnostics (results invalid)
+    const char* dummy_src = reinterpret_cast<const char*>(Whi) + lane * 4;      // 256 contiguous bytes, always mapped
+    auto dummy = [&]() __attribute__((always_inline)) {                           // two pieces, like every issue slot
+        char* dst = smem + WORK_BYTES + TAB_BYTES + wave * 512;
+        __builtin_amdgcn_global_load_lds((gbl_void*)dummy_src, (lds_void*)dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)dummy_src, (lds_void*)(dst + 256), 4, 0, 0);
+    };
     auto issue = [&](int kind, int T, int stage) __attribute__((always_inline)) {
         if (diag_noload && T >= 2) return;
-        const int kt = T < nk ? T : nk - 1;
+        const int kt = T < nk ? T : (WS && kind >= 2 ? nk - 2 : nk - 1);
         const long long kofs = (long long)kt * KB;
         char* dst = smem + stage * STAGE_BYTES + kind * HALF_BYTES + wave * 1024;
         glds16(src[kind][0] + kofs, dst);
@@ -147,6 +168,13 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
             wh[al] = *reinterpret_cast<const bf16x8*>(whi_p + o + al * 2048);
             wl[al] = *reinterpret_cast<const bf16x8*>(wlo_p + o + al * 2048);
         }
+    };
+    // WS: the fragments of K tile `pos` (0 = even tile: hi position, 1 = odd tile: lo position) of the super-tile in `stage`
+    auto read_ws = [&](int stage, int h, int pos, bf16x8 (&wh)[2]) __attribute__((always_inline)) {
+        const int o = stage * STAGE_BYTES + h * HALF_BYTES;
+        const char* base = pos ? wlo_p : whi_p;
+#pragma unroll
+        for (int al = 0; al < 2; ++al) wh[al] = *reinterpret_cast<const bf16x8*>(base + o + al * 2048);
     };
 
     f32x4 acc[4][8];   // [n tile][m tile]
@@ -204,7 +232,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     issue(KW1, 0, 0);
     issue(KX1, 0, 0);
     issue(KX0, 1, 1);
-    issue(KW0, 1, 1);
+    if (WS) dummy(); else issue(KW0, 1, 1);        // WS: tile 1's weights came with tile 0's rows
     if (g.act == AVI_ACT_GELU && wave < 2)
         glds16(reinterpret_cast<const char*>(avi_gelu_tab) + wave * 1024 + lane * 16, smem + WORK_BYTES + wave * 1024);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // X0(0), W0(0), W1(0) have landed
@@ -244,6 +272,78 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
         read_x(u, 1, xh, xl);
         __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (WS) {
+        // K tiles in fours: tile T + v has its X halves in stage v & 1 and its weights in the W areas of stage v >> 1 at
+        // position v & 1.  issue_w(kind, v2): the slot that stages tile T + v2's weights - real for an even tile (into the
+        // W areas of stage (v2 >> 1) & 1), a dummy for an odd one.
+        auto issue_w = [&](int kind, int T, int v2) __attribute__((always_inline)) {
+            if (v2 & 1) dummy(); else issue(kind, T + v2, (v2 >> 1) & 1);
+        };
+        auto rdw1 = [&](int v) __attribute__((always_inline)) {          // W0 + X0 of tile v (mod 4)
+            read_ws((v >> 1) & 1, 0, v & 1, w0h);
+            read_x(v & 1, 0, xh, xl);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rdw2 = [&](int v) __attribute__((always_inline)) {
+            read_ws((v >> 1) & 1, 1, v & 1, w1h);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (wr == 0) {
+            for (int T = 0; T < nk; T += 4) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {               // K tile T + v
+                    const int u = v & 1;
+                    rdw1(v);
+                    quadrant(0, 0, xh, xl, w0h, w0l);
+                    issue_w(KW1, T, v + 1);
+                    mem_top();
+                    bar();
+                    rdw2(v);
+                    quadrant(0, 1, xh, xl, w1h, w1l);
+                    issue(KX1, T + v + 1, u ^ 1);
+                    mem_top();
+                    bar();
+                    rd3(u);
+                    quadrant(1, 1, xh, xl, w1h, w1l);
+                    issue(KX0, T + v + 2, u);
+                    mem_top();
+                    bar();
+                    quadrant(1, 0, xh, xl, w0h, w0l);
+                    issue_w(KW0, T, v + 2);
+                    mem_top();
+                    bar();
+                }
+            }
+        } else {
+            rdw1(0);
+            dummy();                                        // the slot of KW1(1)
+            for (int T = 0; T < nk; T += 4) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int u = v & 1;
+                    quadrant(0, 0, xh, xl, w0h, w0l);
+                    mem_top();
+                    rdw2(v);
+                    issue(KX1, T + v + 1, u ^ 1);
+                    bar();
+                    quadrant(0, 1, xh, xl, w1h, w1l);
+                    mem_top();
+                    rd3(u);
+                    issue(KX0, T + v + 2, u);
+                    bar();
+                    quadrant(1, 1, xh, xl, w1h, w1l);
+                    mem_top();
+                    issue_w(KW0, T, v + 2);
+                    bar();
+                    quadrant(1, 0, xh, xl, w0h, w0l);
+                    mem_top();
+                    rdw1((v + 1) & 3);                      // first phase of the next K tile (a dummy after the last)
+                    issue_w(KW1, T, v + 2);
+                    bar();
+                }
+            }
+        }
+    } else
     if (wr == 0) {
         for (int T = 0; T < nk; T += 2) {
 #pragma unroll
@@ -419,12 +519,12 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
 #endif
 }
 
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, bool WS = false>
 int launch(const AviGemm& g, hipStream_t s) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     static AviLdsGrant lds_grant;
-    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp_kernel<NS, F16>), SMEM_BYTES);
-    hipLaunchKernelGGL((gemm_pp_kernel<NS, F16>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
+    lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp_kernel<NS, F16, WS>), SMEM_BYTES);
+    hipLaunchKernelGGL((gemm_pp_kernel<NS, F16, WS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
                        tilesN);
     return avi_launch_status();
 }
@@ -438,6 +538,11 @@ bool avi_gemm_pp_ok(const AviGemm& g) {
 }
 
 int avi_gemm_pp_launch(const AviGemm& g, hipStream_t s) {
-    if ((g.prec & 0xff) == AVI_PREC_F16X2) return launch<2, true>(g, s);
+    if ((g.prec & 0xff) == AVI_PREC_F16X2) {
+        // weight super-tiles when the K tiles come in fours (every GEMM of the audio path); AVI_GEMM_WS=0: the older staging
+        const char* e = getenv("AVI_GEMM_WS");
+        const bool ws = (g.K % 128) == 0 && !(e && atoi(e) == 0) && !(g.prec & 0x300);
+        return ws ? launch<2, true, true>(g, s) : launch<2, true>(g, s);
+    }
     return (g.prec & 0xff) == AVI_PREC_BF16X3 ? launch<2>(g, s) : launch<1>(g, s);
 }

@@ -459,3 +459,38 @@ def test_stream_k_gemm(gpu, monkeypatch, M, N, K, budget, prec):
     assert float(ws.abs().sum()) > 0
     outp = ops.linear_planes(xp, pw, act=ops.ACT_GELU, residual=rg, prec=prec, out_planes=True, cus=budget, sk_ws=ws)
     assert (outp.float() - out).abs().max().item() < 1e-4 * max(1.0, out.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 512, 1536), (300, 512, 1024), (1000, 768, 768), (257, 3072, 768), (512, 512, 128),
+                                   (300, 512, 192), (300, 512, 320)])
+@pytest.mark.parametrize("tile", ["4", "6"])
+def test_two_term_fp16_gemm_exact_against_rounded_weights(gpu, monkeypatch, tile, M, N, K):
+    """AVI_PREC_F16X2 on the plane-operand kernels (256 x 256: tile "4", incl. its weight super-tile staging for K % 128 == 0
+    and the older staging otherwise; 128 x 256: tile "6"): y = fp16(w) . (x_hi + x_lo).  Against float64 with the weights
+    rounded to fp16 the kernel is fp32-accurate (the format's own error is the weight rounding, pinned at the path level by
+    tests/test_gpu_mixed_prec.py); cold operands, ragged M, K tiles in fours / pairs / threes; and the weight super-tiles
+    give the SAME result as the older staging (AVI_GEMM_WS=0) bit for bit (same products, same accumulation order)."""
+    from avi_talking_amd import ops
+    if tile == "6" and K % 96:
+        pytest.skip("the 128-row kernel takes K tiles in threes")
+    if tile == "4" and K % 64:
+        pytest.skip("the 256-row kernel takes K tiles in pairs")
+    monkeypatch.setenv("AVI_GEMM_KERNEL", tile)
+    x, w, b = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3)
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    w16 = pw.f16_plane().view(torch.float16)[:N].cpu()           # the plane the kernel multiplies (fp16 of bf16 hi + lo)
+    assert (w16.float() - w).abs().max().item() <= 2.0 ** -11 * w.abs().max().item()
+    ref = F.gelu(F.linear(x.double(), w16.double(), b.double()))
+    xp = ops.Planes((M, K), gpu, ops.PLANES_F16)
+    hi = x.to(torch.float16)
+    xp.hi.copy_(hi.view(torch.int16).to(gpu))
+    xp.lo.copy_((x - hi.float()).to(torch.float16).view(torch.int16).to(gpu))
+    outs = {}
+    for ws in ("1", "0"):
+        monkeypatch.setenv("AVI_GEMM_WS", ws)
+        torch.empty(64 << 20, dtype=torch.float32, device=gpu).fill_(1.0)          # evict
+        torch.cuda.synchronize()
+        outs[ws] = ops.linear_planes(xp, pw, act=ops.ACT_GELU, prec=ops.PREC_F16X2).cpu()
+    err = (outs["1"].double() - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), err
+    assert torch.equal(outs["1"], outs["0"])
