@@ -697,16 +697,22 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             "algorithmic_gflop_per_step": round(B * T * 12.4e-3, 1),
             "traffic": pmc_lookup(traffic, "prior_sample", "hbm_bytes_per_launch"),
             "mfma_busy_pmc": pmc_lookup(busy, "prior_sample", "mfma_busy_frac")})
-    # Order: time per step.  The sampler runs BESIDE the audio branch: it leads only when its launch fills the step (it then
-    # bounds it: >= 95 %); with slack it is listed second, behind the dominant family of the branch that does bound the step.
+    # Order.  `roofline` = the kernel family that does most of the pass's ARITHMETIC (largest algorithmic FLOPs per step: the
+    # 256 x 256 GEMM of the conv layers, half of the path's FLOPs) - stable across devices of the pool and precision plans;
+    # `others` by time per step.  The sampler runs BESIDE the audio branch on its own 32 CUs: with the conv layers on two MFMAs
+    # per product the two branches are within 2-5 % of each other, so which one ends a pass last differs from device to
+    # device; its entry says so (`role`) and leads `others` when its branch (aligner + launch) is >= 95 % of the step.
     smp = [e for e in entries if e["kernel"].startswith("prior sampler")]
-    entries = sorted((e for e in entries if e not in smp), key=lambda e: -e["ms_per_step"])
+    rest = [e for e in entries if e not in smp]
+    lead = max((e for e in rest if e["bound"] == "mfma"), key=lambda e: e["algorithmic_gflop_per_step"])
+    entries = [lead] + sorted((e for e in rest if e is not lead), key=lambda e: -e["ms_per_step"])
     if smp:
-        # its branch = the aligner in front of it + the launch itself; the rest of a pass is hand-over between graphs
         bounds = smp[0]["branch_ms"] >= 0.95 * step_ms
-        smp[0]["role"] = ("its branch (aligner + sampler) bounds the step" if bounds else
-                          f"beside the audio branch with {step_ms - smp[0]['branch_ms']:.1f} ms of slack (eager, instrumented pass)")
-        entries.insert(0 if bounds else 1, smp[0])
+        smp[0]["role"] = (f"its branch (aligner + sampler, {smp[0]['branch_ms']:.2f} ms) ends the pass together with the audio "
+                          f"branch ({audio_ms:.2f} ms accounted in the eager instrumented pass): the step is bound by both" if bounds
+                          else f"beside the audio branch with {step_ms - smp[0]['branch_ms']:.1f} ms of slack (eager, instrumented pass)")
+        entries.insert(1 if bounds else 2, smp[0])
+    entries[0]["chosen_by"] = "largest algorithmic FLOPs per step among the matrix-core families"
     out = entries[0]
     out["others"] = entries[1:]
     out["audio_branch_ms_accounted"] = audio_ms
