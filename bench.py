@@ -6,8 +6,11 @@ One "step" = one full pass of the path over one batch of synthetic input residen
   BrainNetwork -> 100-step DDPM prior -> style ; EMOTE head + FLINT decoder -> (32,250,50|3) coefficients.
 This is BASELINE.json configs[1] ("Single MI355X: batch 32 x 10 s clips, 25 fps FLAME coeffs,
 hipGraph-captured loop").  The DDPM loop runs the reference's actual 100 steps: a 50-step run is not a
-configuration the reference object supports.  The whole pass is captured in one
-hipGraph and replayed per step.  Weights are seeded random-init of the reference architectures; data is
+configuration the reference object supports.  The whole pass - the draw of the DDPM noise
+included (device-resident Philox stream, csrc/rng.hip) - is captured in hipGraphs and replayed per step.  Default
+precision plan: `mixed` (conv layers on 2 fp16 MFMAs per product, everything else on 3 bf16 MFMAs: 2.5e-4 on the
+coefficients, gate 3e-4, north_star 1e-3); `precision_modes` times the other plans, all-3-term `bf16x3` (2e-5)
+among them, in the same process.  Weights are seeded random-init of the reference architectures; data is
 synthetic band-limited noise.
 
 Multi-GPU: utterances are independent, so each rank runs its own batch with no data-path collective (weak
@@ -17,8 +20,10 @@ from this script itself: the parent spawns N children (one per GPU, 127.0.0.1 re
 exits with the worst child's code.  `--dry-run` runs the same launcher, rendezvous, barrier and max-over-ranks timing
 on the CPU over gloo with a stand-in step (tests/test_dist_gloo.py): no GPU, no HIP library.
 
-Prints ONE JSON line (see the round contract) with extra objects `roofline` (dominant kernel = the bf16
-MFMA GEMM, HIP-event timed live) and `cpu_baseline` (the CPU oracle on a bounded sample).
+Prints ONE JSON line (see the round contract) with extra objects `roofline` (the matrix-core GEMM family that does most of
+the pass's arithmetic, every launch HIP-event timed live on its own stream; the other families, the HBM-bound launches and
+the sampler under `others`) and `cpu_baseline` (the CPU oracle on a bounded sample), plus secondary legs: precision_modes,
+train, faceformer, longform, flame, clip_text.
 """
 import argparse
 import json
