@@ -56,7 +56,7 @@ class SamplingPipeline:
         self.out_dtype = out_dtype         # float16: the head's last kernel stores the coefficients as IEEE half (configs[4])
         from .rng import DeviceRng
         self.rng = None if rng_seed is None else DeviceRng(rng_seed, self.device)
-        self._noise_buf = None
+        self._noise_bufs = {}          # per batch size, never freed: captured graphs keep writing into theirs
         self.plan = plan = ops.prec_plan(prec)       # AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=plan, joint_norm=joint_norm)
         # the uniform fp16 mode also stores the sampler's attention matrices as one fp16 plane (the mixed plans leave the
@@ -119,11 +119,13 @@ class SamplingPipeline:
         if self.rng is None:
             raise ValueError("noise=None needs a pipeline built with rng_seed=... (in-pass draws)")
         T = self.prior.noise_scheduler.num_timesteps
-        if self._noise_buf is None or self._noise_buf.shape[1] != B:
-            self._noise_buf = torch.empty((T + 1, B, 1, 128), dtype=torch.float32, device=self.device)
-        self.rng.fill(self._noise_buf, R.NORMAL, subsequence=0)
+        buf = self._noise_bufs.get(B)
+        if buf is None:
+            buf = self._noise_bufs[B] = torch.empty((T + 1, B, 1, 128), dtype=torch.float32, device=self.device)
+        self._noise_buf = buf          # the noise of the most recent pass (tests read it back)
+        self.rng.fill(buf, R.NORMAL, subsequence=0)
         self.rng.advance(1)
-        return self._noise_buf
+        return buf
 
     def run(self, pcm, voxel, noise=None):
         """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside

@@ -408,8 +408,13 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
         # data parallel: hipGraph segments cut at the gradient-bucket announcements, the RCCL all-reduces issued eagerly
         # between them (collectives stay outside the graphs), one fused-AdamW launch per bucket as its sum arrives
         graph = "segments (7 graphs) + eager RCCL all-reduce per bucket + per-bucket AdamW"
-        tr.capture_step_dp(voxel, target, temp, rng=DeviceRng(4321 + rank, dev))
-        step = tr.replay_step_dp
+        try:
+            tr.capture_step_dp(voxel, target, temp, rng=DeviceRng(4321 + rank, dev))
+            step = tr.replay_step_dp
+        except Exception as e:      # every rank runs the same code on the same shapes: a capture error is the same on all of
+            graph = f"eager (segment capture failed: {type(e).__name__}: {str(e)[:120]})"      # them, and so is the fallback
+            tr = PriorTrainer(wp, device=dev, lr=1e-4)
+            step = lambda: tr.train_step(voxel, target, temp, rand=rand)
     for _ in range(3):
         out = step()
     torch.cuda.synchronize(dev)
