@@ -8,7 +8,7 @@ with their operands decomposed the way a kernel would hold them:
   mixed        f16x2 on the conv layers only                                              (shipped: --prec mixed, the default)
   f16+fp8x     main term x_hi.w_hi on fp16; BOTH cross terms x_hi.w_lo + x_lo.w_hi on block-scaled fp8 (e4m3, one E8M0
                scale per 32 k) - `v_mfma_scale_f32_16x16x128_f8f6f4` runs 4x the K at 2x the cycles: 2 MFMA-equivalents
-  f16+fp6x     the same with e2m3 operands (4x the K at 1x the cycles): 1.5 MFMA-equivalents
+  f16+fp6x     the same with e2m3 operands: 1.7 MFMA-equivalents (measured issue rate, scripts/probe/mfma_scale_probe.hip)
   f16+fp4x     e2m1: 1.5 MFMA-equivalents
 
 This is the study the round-2 review asked for BEFORE any fp8 cross-term kernel is built: it pins (a) that the
