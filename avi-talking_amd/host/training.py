@@ -851,6 +851,9 @@ class PriorTrainer:
             if rng is None:
                 raise ValueError("capture_step_dp needs rand (recorded draws) or rng (in-graph draws)")
             rand = self.draw(voxel.shape[0])
+        if warmup < 1:
+            raise ValueError("capture_step_dp needs at least one eager warm-up step (workspaces and job tables are built on "
+                             "first use, which a stream capture does not allow)")
         self._static = dict(voxel=voxel.clone(), target=clip_target.clone(),
                             rand={k: ([m.clone() for m in v] if isinstance(v, list) else v.clone())
                                   for k, v in rand.items()})
@@ -898,19 +901,30 @@ class PriorTrainer:
         if len(self._segs) != n_spans:
             raise RuntimeError("the backward pass announced fewer gradient spans than the layout expects")
         self.sync.finish(self.store.G, launch=False)
+        self._dp_stream = stream                  # the chain replays on the stream it was captured on (replay_step_dp)
         torch.cuda.synchronize(self.device)
         return self
 
     def replay_step_dp(self, lr=None, beta1=None):
         self.step_count += 1
-        self._set_dyn(self.lr if lr is None else lr, beta1)
-        G = self.store.G
-        for graph, (first, last) in self._segs:
-            graph.replay()
-            self.sync.ready(G, first, last)                   # eager all-reduce of the bucket this segment completed
-        world = self.sync.world()
-        self.sync.finish(G, on_span=lambda a, b: self._adamw_span(a, b, world, use_dyn=True))
-        self.refresh()
+        cur = torch.cuda.current_stream(self.device)
+        s = self._dp_stream
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            # An explicit stream for the whole chain: the collectives order themselves behind "the work already on the current
+            # stream" through an event recorded when they are issued, and a hipGraph launched on the NULL stream is not
+            # reliably ordered in front of such an event (world-2 run on one GPU: the buckets announced between two segments
+            # were reduced before their segment had finished writing them - wrong sums, sometimes NaN; the bucket behind the
+            # last segment was always right.  tests/test_gpu_dp_world2.py).
+            self._set_dyn(self.lr if lr is None else lr, beta1)
+            G = self.store.G
+            for graph, (first, last) in self._segs:
+                graph.replay()
+                self.sync.ready(G, first, last)                   # eager all-reduce of the bucket this segment completed
+            world = self.sync.world()
+            self.sync.finish(G, on_span=lambda a, b: self._adamw_span(a, b, world, use_dyn=True))
+            self.refresh()
+        cur.wait_stream(s)
         return self._gout
 
     def train_step(self, voxel, clip_target, temp, rand=None, lr=None, beta1=None):

@@ -1,0 +1,130 @@
+"""GPU, TWO processes on the one card: the data-parallel training step end to end with real inter-process collectives.
+
+No second GPU is available to the build, and RCCL refuses two ranks on one device, so the transport here is gloo over CUDA
+tensors - everything ELSE is the shipped multi-rank path: `PriorTrainer.capture_step_dp` / `replay_step_dp` (hipGraph segments
+cut at the gradient-bucket announcements, one async all-reduce per bucket issued between the segments, one fused AdamW per bucket
+as its sum arrives) and the eager `train_step`, each rank on its own batch.  Expected result, computed in ONE process without
+torch.distributed: the two ranks' gradients summed by hand, AdamW with grad_scale 1/2.
+
+This test found a real ordering bug of the segment chain: replayed on the NULL stream, the buckets announced between two
+segments were reduced before their segment had finished writing them (a collective orders itself behind an event recorded on
+the current stream, and a hipGraph launched on the null stream is not reliably in front of that event for another stream's
+wait); the chain now replays on the explicit stream it was captured on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+LRS = (1e-3, 1e-3, 2e-3)          # three optimizer steps in every variant (the segment capture's warm-up step is the first)
+
+
+def _batch(rank, B=64):
+    g = torch.Generator().manual_seed(500 + rank)
+    voxel, target = torch.randn(B, 768, generator=g), torch.randn(B, 1, 128, generator=g) * 0.3
+    rand = dict(times=torch.randint(0, 100, (B,), generator=g).to(torch.int32), noise=torch.randn(B, 128, generator=g),
+                brain_keep=(torch.rand(B, generator=g) < 0.8).to(torch.uint8),
+                image_keep=(torch.rand(B, generator=g) < 0.8).to(torch.uint8),
+                dropout_masks=[(torch.rand(B, 4096, generator=g) >= 0.5).float() / 0.5] +
+                              [(torch.rand(B, 4096, generator=g) >= 0.15).float() / 0.85 for _ in range(4)])
+    return voxel, target, rand
+
+
+def _to(rand, dev):
+    return {k: ([m.to(dev) for m in v] if isinstance(v, list) else v.to(dev)) for k, v in rand.items()}
+
+
+def _worker(rank, world, port, mode, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd.host.training import PriorTrainer
+    from avi_talking_amd.weights import make_prior_weights
+    dev = torch.device("cuda:0")
+    voxel, target, rand = _batch(rank)
+    tr = PriorTrainer(make_prior_weights(3), device=dev, lr=1e-3)
+    assert tr.sync.world() == 2
+    if mode == "segments":
+        tr.capture_step_dp(voxel.to(dev), target.to(dev), 0.005, _to(rand, dev), warmup=1)   # = one eager DP step at lr 1e-3
+        tr.replay_step_dp(lr=1e-3)
+        tr.replay_step_dp(lr=2e-3)
+    else:
+        for lr in LRS:
+            tr.train_step(voxel.to(dev), target.to(dev), 0.005, rand=_to(rand, dev), lr=lr)
+    torch.cuda.synchronize()
+    P = tr.store.P.cpu()
+    gathered = [torch.empty_like(P) for _ in range(world)]
+    dist.all_gather(gathered, P)
+    if rank == 0:
+        ret["P"] = P
+        ret["ranks_equal"] = bool(torch.equal(gathered[0], gathered[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _expected(gpu):
+    """Three steps of the same training, ONE process, no torch.distributed: per step both ranks' gradients (their own batch,
+    the current parameters) summed by hand, then the optimizer with world = 2."""
+    from avi_talking_amd.host.training import PriorTrainer
+    from avi_talking_amd.weights import make_prior_weights
+    tr = PriorTrainer(make_prior_weights(3), device=gpu, lr=1e-3)
+    for lr in LRS:
+        G = torch.zeros_like(tr.store.G)
+        for rank in range(2):
+            voxel, target, rand = _batch(rank)
+            r = _to(rand, gpu)
+            tr.forward_backward(voxel.to(gpu), target.to(gpu), r["times"], r["noise"], 0.005, r["brain_keep"], r["image_keep"],
+                                r["dropout_masks"])
+            tr.sync.finish(tr.store.G)                     # single process: bookkeeping only
+            G += tr.store.G
+        tr.store.G.copy_(G)
+        tr.optimizer_step(lr, world=2)
+    torch.cuda.synchronize()
+    return tr.store.P.cpu()
+
+
+@pytest.mark.parametrize("mode", ["segments", "eager"])
+def test_dp_step_world2_one_gpu(gpu, mode):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    expect = _expected(gpu)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, mode, ret), nprocs=2, join=True)
+    assert ret["ranks_equal"], "the two ranks ended the step with different parameters"
+    P = ret["P"]
+    err = (P - expect).abs().max().item()
+    moved = (expect - PriorTrainerInitial.get()).abs().max().item()
+    print(f"{mode}: world-2 parameters vs the hand-summed single-process step: max-abs {err:.2e} (the three steps moved them by {moved:.2e})")
+    from avi_talking_amd.host.training import FlatLayout, _layout
+    from avi_talking_amd.weights import make_prior_weights
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    worst = sorted(((float((P[lay.offset[n]:lay.offset[n] + w[n].numel()] - expect[lay.offset[n]:lay.offset[n] + w[n].numel()]).abs().max()), n)
+                    for n in lay.names), reverse=True)[:6]
+    print("   largest differences:", [(f"{e:.1e}", n) for e, n in worst])
+    assert err < 0.02 * moved                # float atomics in the null-kv / bias-table gradients + AdamW's m / sqrt(v), as in
+                                             # tests/test_gpu_training.py::test_dp_segment_step_equals_single_graph_step
+
+
+class PriorTrainerInitial:
+    _p = None
+
+    @classmethod
+    def get(cls):
+        if cls._p is None:
+            from avi_talking_amd.host.training import FlatLayout, _layout
+            from avi_talking_amd.weights import make_prior_weights
+            w = make_prior_weights(3)
+            lay = FlatLayout.of_state_dict(w, _layout())
+            P = torch.zeros(lay.numel)
+            for n in lay.names:
+                o = lay.offset[n]
+                P[o:o + w[n].numel()] = w[n].reshape(-1).float()
+            cls._p = P
+        return cls._p

@@ -299,7 +299,10 @@ def test_dp_segment_step_equals_single_graph_step(gpu, setup):
         floor = (x - z).abs().max().item()
         err = (x - y).abs().max().item()
         print(f"{name}: segments vs one graph {err:.2e}, one graph vs itself {floor:.2e} (scale {x.abs().max().item():.2e})")
-        assert err <= max(4.0 * floor, 1e-7 * x.abs().max().item()), (name, err, floor)
+        # yardstick: ten times what two runs of the single-graph path differ by, or - the floor itself is a sample of a
+        # few float-atomic orderings - 2 % of the largest rate for the parameters / 1e-5 of the buffer's scale otherwise
+        bound = max(10.0 * floor, 0.02 * 3e-3 if name == "P" else 1e-5 * x.abs().max().item())
+        assert err <= bound, (name, err, floor, bound)
     recon = seg.store.HI.view(torch.bfloat16).float() + seg.store.LO.view(torch.bfloat16).float()
     assert (recon - seg.store.P).abs().max().item() <= 2e-5 * seg.store.P.abs().max().item()   # planes follow the update
 
