@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event timing (roofline object)")
     ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--legs", default="all", help="comma-separated secondary legs to run (roofline, cpu_baseline, precision_modes, "
+                                                    "faceformer, longform, flame, clip_text, train); default: all")
     ap.add_argument("--secondary-timeout", type=float, default=300.0,
                     help="seconds the roofline / cpu_baseline / flame / train legs may take before the line is printed "
                          "without them (the process then exits with code 3)")
@@ -180,6 +182,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # AVI_BENCH_ONE_GPU_REHEARSAL=1: every rank on GPU 0 with gloo as the transport (RCCL refuses two ranks on one device):
+    # the whole N-rank flow of this script - spawn, barriers, the max-reduce, rank-0-only legs while the other ranks wait in
+    # the training leg's collectives, the DP step with real inter-process all-reduces - on a one-GPU box.  The numbers of such
+    # a run mean nothing (the ranks share the card); the line says so.
+    rehearsal = os.environ.get("AVI_BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if args.dry_run:
         raise SystemExit(dry_run(args, world, rank))
     if not torch.cuda.is_available():
@@ -193,7 +202,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -214,7 +226,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
 
     if args.no_graph:
         step = lambda: pipe.run(pcm, voxel, None)
@@ -252,6 +264,8 @@ def main():
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+        **({"rehearsal": "AVI_BENCH_ONE_GPU_REHEARSAL: all ranks share ONE GPU over gloo - a test of the N-rank flow, NOT a measurement"}
+           if rehearsal else {}),
         "config": {"workload": "configs[1]: 32 clips x 10 s @16 kHz per GPU -> 250 frames @25 fps each; "
                                "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
                    "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
@@ -292,8 +306,10 @@ def main():
     timer.daemon = True
     timer.start()
 
+    legs = None if args.legs == "all" else set(args.legs.split(","))
+
     def run_leg(name, fn, only_rank0=True):
-        if only_rank0 and rank != 0:
+        if (only_rank0 and rank != 0) or (legs is not None and name not in legs):
             return
         leg["name"] = name
         try:
@@ -418,15 +434,16 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
     for _ in range(3):
         out = step()
     torch.cuda.synchronize(dev)
+    bar = lambda: (dist.barrier() if os.environ.get("AVI_BENCH_ONE_GPU_REHEARSAL") == "1" else dist.barrier(device_ids=[local_rank]))
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        bar()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         out = step()
     torch.cuda.synchronize(dev)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        bar()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -49,3 +49,27 @@ def test_cli_train_mode_writes_and_resumes_checkpoint(gpu, tmp_path):
                        capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     assert torch.load(path, map_location="cpu", weights_only=True)["epoch"] == 3
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` end to end with two REAL rank processes on the one card (AVI_BENCH_ONE_GPU_REHEARSAL=1: gloo
+    as the transport, RCCL refuses two ranks on one device): the launcher, the rendezvous, the barriers and the max-reduce
+    around the timed region, and the data-parallel training leg (hipGraph segments + one all-reduce per gradient bucket between
+    two processes).  One JSON line from rank 0 with n_gpus = 2; the numbers are not measurements and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AVI_BENCH_ONE_GPU_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--train-steps", "3", "--legs", "train"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and "rehearsal" in rec and rec["value"] > 0
+    tr = rec["train"]
+    assert tr["global_batch"] == 128 and "segments" in str(tr["hipgraph"]) and tr["loss_prior"] == tr["loss_prior"]
+    assert len(tr["gradient_buckets"]) == 7
