@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gelu_table.h"
 
 namespace {
 
@@ -39,7 +40,8 @@ template <int NT> struct Geo {
     static constexpr int STAGE_BYTES = 2 * X_BYTES + W_BYTES;          // 40 / 48 KiB
     static constexpr int EP_STRIDE = 64 * NT + 16;                     // epilogue slab row: 16 NT fp32 + 16 B pad
     static constexpr int EP_SLAB = 64 * EP_STRIDE;
-    static constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;            // 120 / 144 KiB (>= 8 slabs = 104 / 136 KiB)
+    static constexpr int WORK_BYTES = NSTAGE * STAGE_BYTES;            // 120 / 144 KiB (>= 8 slabs = 104 / 136 KiB)
+    static constexpr int SMEM_BYTES = WORK_BYTES + AVI_GELU_TAB_BYTES; // + the GELU table of the epilogue (gelu_table.h)
 };
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 4 && N <= 6, "vmcnt literal");
@@ -284,6 +286,12 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
             }
         }
     }
+    // GELU in the epilogue comes from the same LDS table as in the 256 x 256 kernel (gemm_pp.hip), so that a projection's
+    // result does not depend on which tile shape the dispatcher picked for its M and CU budget; fetched here, as the
+    // youngest load in front of the drain below (the tail DMAs are still landing: it costs no wait of its own)
+    if (g.act == AVI_ACT_GELU && wave < 2)
+        glds16(reinterpret_cast<const char*>(avi_gelu_tab) + wave * 1024 + lane * 16,
+               smem + Geo<NT>::WORK_BYTES + wave * 1024);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();                                               // every wave's tail DMA has landed: the stages are dead
 
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
         for (int j = 0; j < 4; ++j) v[j] = r0[j] + ((bias && n + j < g.N) ? bias[n + j] : 0.f);
         if (g.act == AVI_ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = avi_gelu(v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = avi_gelu_lds(v[j], smem + Geo<NT>::WORK_BYTES);
         } else if (g.act != AVI_ACT_NONE) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = avi_act(v[j], g.act);

@@ -272,7 +272,10 @@ class InstructDiffusionPrior:
         self.samples_per_group = int(os.environ.get("AVI_PRIOR_SPG", "1"))
         # PAIRED sampler (csrc/prior_pair.hip): two samples on two CUs, each streaming half of every matrix; needs the
         # default plane formats (feed-forward fp16, attention bf16 hi / lo).  AVI_PRIOR_PAIR=0/1 overrides.
-        self.paired = os.environ.get("AVI_PRIOR_PAIR", "0") == "1" and net.ff_fp16 and not net.attn_fp16
+        # Default on for batches of up to PAIR_MAX_BATCH samples (64 CUs): beyond that the audio branch, not the sampler,
+        # bounds a pass and the CUs are worth more there.
+        self.paired = os.environ.get("AVI_PRIOR_PAIR", "1") == "1" and net.ff_fp16 and not net.attn_fp16
+        self.pair_max_batch = int(os.environ.get("AVI_PRIOR_PAIR_MAX_BATCH", "32"))
         self._pair_ws = {}
 
     @classmethod
@@ -280,6 +283,16 @@ class InstructDiffusionPrior:
         net = VersatileDiffusionPriorNetwork(state_dict, device=device, timesteps=timesteps, attn_fp16=attn_fp16)
         v2c = BrainNetwork(state_dict, device=device, prec=prec)
         return cls(net, voxel2clip=v2c, timesteps=timesteps, device=device)
+
+    def uses_pairs(self, B):
+        return self.paired and self.samples_per_group > 0 and B <= self.pair_max_batch
+
+    def cus_held(self, B):
+        """Compute units the sampler's workgroups occupy from launch to the end of the loop (one workgroup per CU)."""
+        if self.uses_pairs(B):
+            return 2 * B
+        spg = self.samples_per_group
+        return B if spg <= 0 else (B + min(spg, B) - 1) // min(spg, B)
 
     def pair_status(self):
         """After a synchronisation: raises if a paired-sampler launch saw a partner that never answered (bounded spin)."""
@@ -336,7 +349,7 @@ class InstructDiffusionPrior:
             L.check(L.load().avi_prior_sample(C.byref(self.net.cw), te.data_ptr(), noise.data_ptr(), B,
                                               1.0 / self.image_embed_scale, out.data_ptr(), temb.data_ptr(),
                                               L.stream_ptr()), "avi_prior_sample")
-        elif self.paired and samples_per_group is None:
+        elif self.uses_pairs(B) and samples_per_group is None:
             ws = self._pair_ws.get(B)
             if ws is None:        # zero-filled once, then owned by the library (launch epoch + exchange slots)
                 nbytes = L.load().avi_prior_pair_workspace_bytes(B)

@@ -33,8 +33,9 @@ _DEVICE_STREAMS = {}
 
 
 def device_streams(device):
-    """{'side': high-priority stream of the sampler's branch, 'pool': candidate replay streams, 'pick': index of the head's
-    stream in the pool (None until the first capture_pipelined on the device has timed the candidates)}."""
+    """{'side': high-priority stream of the sampler's branch, 'pool': candidate replay streams (pool[0] replays the body's
+    audio branch), 'picks': {encoder chains: {'head': index of the head's stream in the pool, 'chains': indices of the
+    further chains' streams, 'timings_ms': ...}} (filled by the first capture_pipelined on the device that needs it)}."""
     device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _DEVICE_STREAMS.get(key)
@@ -42,7 +43,7 @@ def device_streams(device):
         st = _DEVICE_STREAMS[key] = {
             # high priority: the sampler's 32 workgroups must get their CUs at once, not behind a round of GEMM tiles
             "side": torch.cuda.Stream(device=device, priority=-1),
-            "pool": [torch.cuda.Stream(device=device) for _ in range(5)], "pick": None, "timings_ms": None}
+            "pool": [torch.cuda.Stream(device=device) for _ in range(8)], "picks": {}}
     return st
 
 
@@ -104,8 +105,7 @@ class SamplingPipeline:
                                              noise=noise)
         # the sampler's workgroups (one per samples_per_group samples) hold a CU each until the join: GEMM tile shapes of the
         # audio branch are chosen for the CUs that remain (avi_talking.h AviGemm.cus)
-        spg = max(1, min(self.prior.samples_per_group, B))
-        free_cus = 256 - (B + spg - 1) // spg if self.prior.samples_per_group > 0 else 256 - B
+        free_cus = max(32, 256 - self.prior.cus_held(B))
         sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B},
                                                  cus=free_cus)
         # 3. join
@@ -158,7 +158,7 @@ class SamplingPipeline:
         return self._out
 
     # ---- software-pipelined replay: the serial end of a pass runs beside its successor
-    def capture_pipelined(self, pcm, voxel, noise=None, warmup=2):
+    def capture_pipelined(self, pcm, voxel, noise=None, warmup=2, arrangements=None):
         """Two graphs instead of one.  A pass ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip
         almost idle) and begins with the aligner (0.19 ms of split-K launches that depend on the text feature alone).
         Captured as `body` and `head` and replayed on two streams, the head of pass k runs beside the start of pass k+1;
@@ -172,64 +172,207 @@ class SamplingPipeline:
         (0.19 ms per pass on the critical path, scripts/pass_timeline.py --gap)."""
         from .. import lib as L
         self._static = (pcm.clone(), voxel.clone(), None if noise is None else noise.clone())
-        for _ in range(warmup):
-            self.run(*self._static)
-        torch.cuda.synchronize(self.device)
         dev = self.device
         self._e_body, self._e_taken = (torch.cuda.Event() for _ in range(2))
-        self._g_body = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_body):
-            self._feat, self._style = self._body(*self._static, aligner_on_side=True)
-        self._h_feat, self._h_style = torch.empty_like(self._feat), torch.empty_like(self._style)
-        self._g_head = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_head):       # pools are NOT shared: the two graphs run concurrently
-            self._pout = self.talking_head.head(self._h_feat, self._h_style, out_dtype=self.out_dtype)
-            self._pout["style_emb"] = self._h_style
 
         def copy(src, dst):
             C_ = src.shape[-1]
             L.check(L.load().avi_copy_rows(src.data_ptr(), C_, None, dst.data_ptr(), C_, src.numel() // C_, C_,
                                            L.stream_ptr()), "avi_copy_rows")
         self._copy = copy
-        self._pick_streams()
+        cands = self._arrangements(pcm.shape[0], pcm.shape[1] // 640) if arrangements is None else list(arrangements)
+        for _ in range(warmup):
+            self.run(*self._static)
+        torch.cuda.synchronize(dev)
+        timed, best, self._g_head = {}, None, None
+        for chains, paired in cands:
+            body = self._capture_body(chains, paired)
+            if self._g_head is None:   # the head reads private copies of the body's results: one capture serves every candidate
+                self._h_feat, self._h_style = torch.empty_like(body.feat), torch.empty_like(body.style)
+                self._g_head = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g_head):
+                    self._pout = self.talking_head.head(self._h_feat, self._h_style, out_dtype=self.out_dtype)
+                    self._pout["style_emb"] = self._h_style
+            self._pbody = body
+            self._pick_streams()
+            ms = self._time_replays() if len(cands) > 1 else 0.0
+            timed[f"chains={chains},paired={int(paired)}"] = round(ms, 3)
+            if best is None or ms < best[0]:
+                best = (ms, body)
+        self._pbody = body = best[1]
+        self._pick_streams()              # the kept arrangement's streams (cached per chain count: nothing is timed again)
+        self.talking_head.audio_model.split_streams, self.prior.paired = body.chains, body.paired
+        self._feat, self._style = body.feat, body.style
+        self.arrangement = {"encoder_chains": body.chains, "paired_sampler": bool(body.paired),
+                            "candidate_ms_per_pass": timed}
         torch.cuda.synchronize(dev)
         return self
+
+    def _capture_body(self, chains, paired):
+        """The body of a pass as one graph PER BRANCH - the sampler's branch (noise draw, aligner, DDPM loop), the audio front
+        (normalisation ... positional conv) and the 12 layers of each group of clips - replayed on a stream each and tied
+        together with events (`_enqueue_body`).  One multi-branch graph was the first design and is what `capture()` still
+        records: there the runtime maps the branches onto internal streams of its own, and with a third branch the audio
+        branch of pass k+1 started 0.2-0.5 ms late, behind the aligner of the sampler's branch (kernel trace,
+        scripts/pass_timeline.py) - which queue a branch lands on is not ours to choose inside a graph, on streams it is."""
+        from types import SimpleNamespace
+        pcm, voxel, noise = self._static
+        B, T = pcm.shape[0], pcm.shape[1] // 640
+        if B % chains:
+            raise ValueError(f"{B} clips do not split into {chains} encoder chains")
+        th, am = self.talking_head, self.talking_head.audio_model
+        self.prior.paired = paired
+        cus = max(32, 256 - self.prior.cus_held(B))
+        per = B // chains
+
+        def side():
+            nz = self._draw_noise(B) if noise is None else noise
+            clip_voxels, _ = self.prior.voxel2clip(voxel, need_projection=False)
+            return self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
+                                            cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps, noise=nz)
+
+        def front():
+            return th.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B}, cus=cus, front_only=True)
+
+        # every launch shape once outside a capture (kernel attributes such as LDS grants are set on first use)
+        side()
+        h = front()
+        for i in range(chains):
+            am.encoder_layers(h[i * per:(i + 1) * per], cus)
+        torch.cuda.synchronize(self.device)
+        body = SimpleNamespace(chains=chains, paired=paired, g_side=torch.cuda.CUDAGraph(), g_front=torch.cuda.CUDAGraph(),
+                               g_chain=[torch.cuda.CUDAGraph() for _ in range(chains)],
+                               e_in=torch.cuda.Event(), e_side=torch.cuda.Event(), e_front=torch.cuda.Event(),
+                               e_chain=[torch.cuda.Event() for _ in range(chains)], streams=None)    # streams: _pick_streams
+        with torch.cuda.graph(body.g_side):
+            body.style = side()
+        with torch.cuda.graph(body.g_front):
+            body.h = front()
+        body.feat = torch.empty_like(body.h)
+        for i, g in enumerate(body.g_chain):
+            with torch.cuda.graph(g):
+                body.feat[i * per:(i + 1) * per].copy_(am.encoder_layers(body.h[i * per:(i + 1) * per], cus))
+        return body
+
+    def _enqueue_body(self, new_inputs):
+        """On the body's stream A (current).  What a pass must wait for, and no more:
+          * the audio front reads the static PCM and writes only its own buffers: it follows the previous pass's chains on A
+            with NO cross-stream dependency - the audio branch, which bounds the pass, runs back to back;
+          * the chains' last launch overwrites `feat` and the sampler's last step `style`, which the previous head copies
+            when it starts: the chains and the sampler's branch wait for `_e_taken` (long past when they get there);
+          * the sampler's branch reads the static text feature / noise: it waits for this call's copies only if there
+            were any.  It is launched first (its workgroups must get their CUs before a round of GEMM tiles does).
+        Leaves `_e_body` recorded on A."""
+        b, A, S = self._pbody, self._s_body, self.side
+        if new_inputs:
+            b.e_in.record(A)
+        with torch.cuda.stream(S):
+            if new_inputs:
+                S.wait_event(b.e_in)
+            S.wait_event(self._e_taken)
+            b.g_side.replay()
+            b.e_side.record(S)
+        b.g_front.replay()
+        b.e_front.record(A)
+        for i, C in enumerate(b.streams, 1):
+            with torch.cuda.stream(C):
+                C.wait_event(b.e_front)
+                C.wait_event(self._e_taken)
+                b.g_chain[i].replay()
+                b.e_chain[i].record(C)
+        A.wait_event(self._e_taken)
+        b.g_chain[0].replay()
+        for i in range(1, b.chains):
+            A.wait_event(b.e_chain[i])
+        A.wait_event(b.e_side)
+        self._e_body.record(A)
+
+    def _arrangements(self, B, T):
+        """Candidate (encoder chains, paired sampler) arrangements of a pass, best guess first.  Only the CHAIN COUNT is left
+        to timing - results are bit-identical across chain counts, so a choice made with a stopwatch cannot change what a
+        pass returns - and it is timed because which count is fastest depends on how the runtime maps the pass's
+        concurrent branches (sampler, encoder chains, previous head) onto its in-order hardware queues: two branches on one
+        queue serialise.  The sampler kernel is NOT timed: paired and plain differ by 1-3e-6 in the style vector, so that
+        choice follows a fixed rule (`prior.uses_pairs`: paired up to 32 samples).  AVI_W2V_SPLIT pins the chain count."""
+        from .. import HW_QUEUES
+        from .wav2vec import SPLIT_MIN_ROWS
+        am = self.talking_head.audio_model
+        fits = lambda n: n >= 1 and B % n == 0 and (n == 1 or B * T >= n * SPLIT_MIN_ROWS)
+        if os.environ.get("AVI_W2V_SPLIT") is not None:
+            chains = [am.split_streams if fits(am.split_streams) else 1]
+        elif HW_QUEUES >= 8 and fits(2):
+            chains = [2, 1]
+        else:
+            chains = [1]
+        return [(c, self.prior.paired) for c in chains]
+
+    def _time_replays(self, replays=6):
+        import time
+        for _ in range(2):
+            self.replay_pipelined()
+        torch.cuda.synchronize(self.device)
+        t = time.perf_counter()
+        for _ in range(replays):
+            self.replay_pipelined()
+        torch.cuda.synchronize(self.device)
+        return (time.perf_counter() - t) / replays * 1e3
 
     def _pick_streams(self, replays=4):
         """HIP multiplexes streams onto a few IN-ORDER hardware queues, and which queue a stream gets is not ours to choose:
         with the head's stream on the body's queue the head runs between two bodies instead of beside the next one
-        (+0.5 ms per pass in the kernel trace; with the aligner as a third graph it was the aligner, +0.19 ms).  The
-        graphs do not care which stream replays them, so the (body, head) pairs of the device's stream pool are TIMED
-        over a few replays ONCE PER DEVICE, the fastest is kept in ``device_streams(device)`` and every later capture
-        on the device - this object's or another's - reuses it without measuring again: the choice is deterministic for
-        the life of the process and visible as ``self.stream_choice`` (scripts/pass_timeline.py --gap shows the queue of
-        every launch in the hand-over)."""
+        (+0.5 ms per pass in the kernel trace), and an encoder chain on the sampler's queue waits for the whole DDPM loop
+        (+3 ms).  The graphs do not care which stream replays them, so the roles - head, further encoder chains - are
+        given streams of the device's pool by TIMING a few replays per candidate, one role at a time, ONCE PER DEVICE and
+        chain count; the result is kept in ``device_streams(device)`` and every later capture on the device - this
+        object's or another's - reuses it without measuring again: the choice is deterministic for the life of the
+        process and visible as ``self.stream_choice`` (scripts/pass_timeline.py --gap shows the queue of every launch)."""
         import time
         dev = self.device
         st = device_streams(dev)
-        pool = st["pool"]
-        if st["pick"] is None:
-            timings = []
-            for k in range(1, len(pool)):
-                self._s_body, self._s_head = pool[0], pool[k]
+        pool, body = st["pool"], self._pbody
+        n_extra = body.chains - 1
+        if n_extra + 2 > len(pool):
+            raise ValueError(f"{body.chains} encoder chains need {n_extra + 2} replay streams, the pool has {len(pool)}")
+        pick = st["picks"].get(body.chains)
+        if pick is None:
+            roles = list(range(1, n_extra + 2))          # pool indices of [chain 1, ..., chain n, head]: first guess
+            log = []
+
+            def timed():
+                self._s_body, self._s_head = pool[0], pool[roles[-1]]
+                body.streams = [pool[i] for i in roles[:-1]]
                 self.replay_pipelined()
                 torch.cuda.synchronize(dev)
                 t = time.perf_counter()
                 for _ in range(replays):
                     self.replay_pipelined()
                 torch.cuda.synchronize(dev)
-                timings.append((time.perf_counter() - t) / replays * 1e3)
-            st["pick"] = 1 + min(range(len(timings)), key=timings.__getitem__)
-            st["timings_ms"] = [round(t, 3) for t in timings]
-        self._s_body, self._s_head = pool[0], pool[st["pick"]]
-        self.stream_choice = {"body": 0, "head": st["pick"], "candidate_ms_per_pass": st["timings_ms"]}
+                return (time.perf_counter() - t) / replays * 1e3
+
+            for r in range(len(roles)):                  # one role at a time, the others fixed
+                best = None
+                for k in range(1, len(pool)):
+                    if k in roles[:r] + roles[r + 1:]:
+                        continue
+                    roles[r] = k
+                    ms = timed()
+                    log.append((list(roles), round(ms, 3)))
+                    if best is None or ms < best[0]:
+                        best = (ms, k)
+                roles[r] = best[1]
+            pick = st["picks"][body.chains] = {"head": roles[-1], "chains": roles[:-1], "timings_ms": log}
+        self._s_body, self._s_head = pool[0], pool[pick["head"]]
+        body.streams = [pool[i] for i in pick["chains"]]
+        self.stream_choice = {"body": 0, "head": pick["head"], "chains": pick["chains"],
+                              "candidate_ms_per_pass": pick["timings_ms"]}
 
     def replay_pipelined(self, pcm=None, voxel=None, noise=None):
         """Enqueue one pass; returns its output dict (valid once the device, or `self._s_head`, has been synchronised).
         ``pcm`` / ``voxel`` / ``noise``: the next batch, copied into the static input buffers on the body's stream in front
         of the replay (same contract as ``replay``; None = keep what the buffer holds).  The copy is ordered behind the
         previous body by the stream, so a caller may hand over batch k+1 while pass k is still running."""
-        if pcm is not None or voxel is not None or noise is not None:
+        new_inputs = pcm is not None or voxel is not None or noise is not None
+        if new_inputs:
             self._s_body.wait_stream(torch.cuda.current_stream(self.device))   # the caller's stream produced the new inputs
         with torch.cuda.stream(self._s_body):
             for dst, src in zip(self._static, (pcm, voxel, noise)):
@@ -240,13 +383,11 @@ class SamplingPipeline:
                         raise ValueError(f"replay_pipelined: input {tuple(src.shape)} {src.dtype} does not match the "
                                          f"captured {tuple(dst.shape)} {dst.dtype}")
                     dst.copy_(src, non_blocking=True)
-            self._s_body.wait_event(self._e_taken)       # the previous head has copied the previous body's results
-            self._g_body.replay()
-            self._e_body.record(self._s_body)
+            self._enqueue_body(new_inputs)
         with torch.cuda.stream(self._s_head):
             self._s_head.wait_event(self._e_body)
-            self._copy(self._feat, self._h_feat)
-            self._copy(self._style, self._h_style)
+            self._copy(self._pbody.feat, self._h_feat)
+            self._copy(self._pbody.style, self._h_style)
             self._e_taken.record(self._s_head)
             self._g_head.replay()
         return self._pout

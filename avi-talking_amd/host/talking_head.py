@@ -189,8 +189,10 @@ class TalkingHeadWrapper:
         self.head = EmoteHead(head_state_dict, device=device, prec=ops.fp32_operand_prec(prec))
         self.joint_norm = joint_norm        # AudioEncoders.py:170-178: HF processor sees ONE (B*L) array
 
-    def forward_audio(self, sample, cus=0):
-        """Wav2Vec2Encoder._forward (AudioEncoders.py:165-200).  ``cus``: compute units free for the big GEMMs (0 = all)."""
+    def forward_audio(self, sample, cus=0, front_only=False):
+        """Wav2Vec2Encoder._forward (AudioEncoders.py:165-200).  ``cus``: compute units free for the big GEMMs (0 = all).
+        ``front_only``: stop in front of the 12 transformer layers and return their input (B, T, 768) instead of the sample
+        (the pipelined replay runs the layers of two groups of clips as separate graphs: audio_model.encoder_layers)."""
         if "raw_audio" in sample:
             raw = sample["raw_audio"].to(self.device)
             B, T = raw.shape[0], raw.shape[1]
@@ -202,6 +204,8 @@ class TalkingHeadWrapper:
         else:
             x = sample["processed_audio"].to(self.device, torch.float32).contiguous()
             T = sample.get("frame_num")
+        if front_only:
+            return self.audio_model.front(x, frame_num=T, cus=cus)
         out = self.audio_model(x, frame_num=T, cus=cus)
         sample["audio_feature"] = out.last_hidden_state
         return sample

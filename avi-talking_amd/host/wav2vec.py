@@ -19,6 +19,7 @@ from .. import ops
 CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
 CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
 HIDDEN, HEADS, LAYERS, POS_K, POS_G = 768, 12, 12, 128, 16
+SPLIT_MIN_ROWS = int(os.environ.get("AVI_W2V_SPLIT_MIN_ROWS", "2000"))   # rows (clips x frames) per encoder chain
 
 
 def conv_out_lengths(n):
@@ -53,6 +54,13 @@ class Wav2Vec2Model:
         # gemm_pp192.hip), so the 400 MB workspace is only allocated on request (AVI_W2V_STREAMK=1 + AVI_GEMM_STREAMK=1/2)
         self.stream_k = os.environ.get("AVI_W2V_STREAMK", "0") == "1"
         self._sk_ws = None
+        # the 12 transformer layers as independent chains of clips on separate streams (_encoder_layers_split):
+        # AVI_W2V_SPLIT = number of chains; default 2 when the process has the hardware queues for it and the batch is
+        # big enough that half of it still fills the chip's tiles (>= SPLIT_MIN_ROWS rows per chain)
+        from .. import HW_QUEUES
+        env = os.environ.get("AVI_W2V_SPLIT")
+        self.split_streams = int(env) if env is not None else (2 if HW_QUEUES >= 8 else 1)
+        self._split_streams = []
         w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
              if v.is_floating_point()}
         fe = "feature_extractor.conv_layers."
@@ -123,12 +131,15 @@ class Wav2Vec2Model:
         seq_len = L50 / 50.0
         return int(seq_len * 25) if self.length_mode == "int" else int(math.ceil(seq_len * 25))
 
-    def encoder(self, hp, cus=0):
+    def encoder(self, hp, cus=0, _inner=False):
+        return self._encoder_layers(self.pos_embed(hp), cus, _inner)
+
+    def pos_embed(self, hp):
+        """hp + GELU(grouped positional conv(hp)): the input of the 12 layers."""
         B, T, _ = hp.shape
         cg = HIDDEN // POS_G
         if self.posconv_kernel:      # one launch, the input window resident in LDS (csrc/posconv.hip)
-            h = ops.posconv_gelu_residual(hp, self.pos, self.pos_bias, POS_G, POS_K, 64)
-            return self._encoder_layers(h, cus)
+            return ops.posconv_gelu_residual(hp, self.pos, self.pos_bias, POS_G, POS_K, 64)
         xg = ops.group_pad_pack(hp, POS_G, POS_K // 2)
         h = torch.empty_like(hp)
         Tp = T + POS_K
@@ -137,9 +148,23 @@ class Wav2Vec2Model:
                      R=hp.data_ptr(), ldr=HIDDEN, act=ops.ACT_GELU, prec=self.prec, batch=B * POS_G, z_inner=POS_G,
                      sA=(POS_G * Tp * cg, Tp * cg), sW=(0, 64 * POS_K * cg), sC=(T * HIDDEN, cg), sB=(0, cg),
                      sR=(T * HIDDEN, cg))
-        return self._encoder_layers(h, cus)
+        return h
 
-    def _encoder_layers(self, h, cus=0):
+    # the pass in two stages, for callers that run the layers of different clips as separate launches / graphs
+    # (host/pipeline.py capture_pipelined): front(x) -> h, then encoder_layers(h[a:b]) per group of clips
+    def front(self, input_values, frame_num=None, cus=0):
+        x = input_values.to(self.device, torch.float32).contiguous()
+        feats = self.feature_extractor(x, cus)
+        T = self.output_length(feats.shape[1], frame_num)
+        h25 = ops.interp_layernorm(feats, T, self.fp_g, self.fp_b)
+        return self.pos_embed(ops.linear(h25, self.proj, prec=self.prec))
+
+    def encoder_layers(self, h, cus=0):
+        """The 12 layers on the clips of ``h`` (B', T, 768) - rows of different clips never meet in them - as ONE chain on the
+        current stream (no fan-out); overwrites ``h``."""
+        return self._encoder_layers(h, cus, _inner=True)
+
+    def _encoder_layers(self, h, cus=0, _inner=False):
         d = HIDDEN // HEADS
         if not self.use_planes_tf:
             h = ops.layernorm(h, self.enc_g, self.enc_b, out=h)
@@ -163,6 +188,9 @@ class Wav2Vec2Model:
             if self._sk_ws is None or self._sk_ws[0] != M:
                 self._sk_ws = (M, ops.stream_k_workspace(M, 3 * HIDDEN, self.device))
             ws = self._sk_ws[1]
+        if (self.split_streams > 1 and not _inner and h.shape[0] % self.split_streams == 0
+                and h.shape[0] * h.shape[1] >= self.split_streams * SPLIT_MIN_ROWS):
+            return self._encoder_layers_split(h, cus)
         h, hp_ = ops.layernorm_planes(h, self.enc_g, self.enc_b, out=h, fmt=FA)
         d = HIDDEN // HEADS
         for ly in self.layers:   # every projection on the ping-pong GEMMs, every activation split once
@@ -174,6 +202,31 @@ class Wav2Vec2Model:
             h = ops.linear_planes(f, ly.ff2, residual=h, prec=PF, cus=cus, sk_ws=ws)
             h, hp_ = ops.layernorm_planes(h, *ly.ln2, out=h, fmt=FA)
         return h
+
+    def _encoder_layers_split(self, h, cus):
+        """The 12 layers as ``split_streams`` independent chains of clips, one stream each: the fixed part of every launch
+        (pipeline fill, the epilogue's burst of stores when all tiles of a one-round GEMM end together, the launch gap)
+        of one chain overlaps the matrix loop of another.  Same kernels, same per-row arithmetic: bit-identical.
+        Memory: the result is allocated on the LAUNCH stream before the fork (its consumers run there; a block owned by a
+        side stream would go back to that stream's pool while they still read it) and the side streams' use of it and of
+        the input is recorded; everything a chain allocates lives and dies on its own stream."""
+        n = self.split_streams
+        cur = torch.cuda.current_stream(self.device)
+        while len(self._split_streams) < n - 1:
+            self._split_streams.append(torch.cuda.Stream(self.device))
+        per = h.shape[0] // n
+        out = torch.empty_like(h)
+        for i in list(range(1, n)) + [0]:                # chain 0 last, on the launch stream
+            st = cur if i == 0 else self._split_streams[i - 1]
+            if i:
+                st.wait_stream(cur)
+                h.record_stream(st)
+                out.record_stream(st)
+            with torch.cuda.stream(st):
+                out[i * per:(i + 1) * per].copy_(self._encoder_layers(h[i * per:(i + 1) * per], cus, _inner=True))
+        for i in range(1, n):
+            cur.wait_stream(self._split_streams[i - 1])
+        return out
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, frame_num=None, cus=0):

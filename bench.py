@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+import avi_talking_amd  # noqa: E402,F401  before the first CUDA call: the package asks the runtime for 8 hardware queues
 
 B_CLIPS, SECONDS, FPS = 32, 10, 25
 N_SAMPLES = SECONDS * 16000
@@ -326,6 +327,7 @@ def main():
     ref_out = {k: o_ref[k].clone() for k in ("predicted_exp", "predicted_jaw")}
     del o_ref
     line["config"]["replay_streams"] = getattr(pipe, "stream_choice", None)
+    line["config"]["arrangement"] = getattr(pipe, "arrangement", None)      # encoder chains x sampler kernel, timed at capture
     del pipe, out
     torch.cuda.empty_cache()
     if not args.no_train and world == 1:      # N = 1 only, like the CPU baseline

@@ -18,6 +18,11 @@ for a, b in list(zip(A, A[1:]))[-5:]:
     enc = [r for r in inside if "gemm_pp192" in r["Kernel_Name"]]
     if not smp or not enc:
         continue
+    prev_end = max((t1(r) for r in rows if t1(r) <= t0(a) and ("gemm_pp192" in r["Kernel_Name"] or "layernorm_kernel<4, true>" in r["Kernel_Name"])), default=None)
+    first_side = min((t0(r) for r in inside if "rng_fill" in r["Kernel_Name"] or "prior_sample" in r["Kernel_Name"]), default=t0(a))
+    if prev_end is not None:
+        print(f"   hand-over: previous pass's last encoder projection ended {(t0(a) - prev_end) / 1e3:.0f} us before this pass's first "
+              f"audio kernel; the sampler branch's first kernel starts {(first_side - t0(a)) / 1e3:+.0f} us from it")
     print(f"pass {(t0(b) - t0(a)) / 1e6:.3f} ms | sampler {(t1(smp[0]) - t0(smp[0])) / 1e6:.3f} ms, ends {(t0(b) - t1(smp[0])) / 1e3:.0f} us "
           f"before the next pass | last encoder projection ends {(t0(b) - max(t1(r) for r in enc)) / 1e3:.0f} us before it")
 if len(sys.argv) > 2 and len(A) > 3:     # --gap: the hand-over in detail

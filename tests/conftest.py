@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+import avi_talking_amd  # noqa: E402,F401  before any test touches the GPU: the package sets the runtime's hardware-queue count
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -181,8 +181,69 @@ def test_second_pipeline_replays_as_fast(gpu):
     t_second = min(timed(second) for _ in range(2))
     t_first_again = min(timed(first) for _ in range(2))
     st = device_streams(gpu)
-    assert second.side is first.side and second._s_body is first._s_body and second._s_head is first._s_head
-    assert first.stream_choice["head"] == second.stream_choice["head"] == st["pick"]
+    assert second.side is first.side and second._s_body is first._s_body
+    if first.arrangement["encoder_chains"] == second.arrangement["encoder_chains"]:     # picks are kept per chain count
+        pick = st["picks"][first.arrangement["encoder_chains"]]
+        assert second._s_head is first._s_head
+        assert first.stream_choice["head"] == second.stream_choice["head"] == pick["head"]
+        assert first.stream_choice["chains"] == second.stream_choice["chains"] == pick["chains"]
     print(f"first {t_first:.3f} ms, second object {t_second:.3f} ms, first again {t_first_again:.3f} ms per pass; "
-          f"stream pick {st['pick']} of candidates {st['timings_ms']}")
+          f"arrangements {first.arrangement} / {second.arrangement}; stream picks {st['picks']}")
     assert t_second < 1.03 * t_first and t_first_again < 1.03 * t_first
+
+
+def test_encoder_chains_are_bit_identical(gpu):
+    """The 12 encoder layers as 2 or 4 chains of clips on separate streams (host/wav2vec._encoder_layers_split) return
+    bit for bit what one chain returns - eagerly, call after call with the results consumed and dropped on the launch
+    stream in between (the gathered result used to be a block of a side stream's pool: freed while its readers on the
+    launch stream were still queued, it was handed to the next call's chain and the first 16 clips came out wrong), and
+    under graph capture."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.wav2vec import Wav2Vec2Model
+    m = Wav2Vec2Model(W.make_wav2vec2_weights(0), device=gpu, prec="mixed", length_mode="ceil")
+    x = (torch.randn(32, 160000, generator=torch.Generator().manual_seed(3)) * 0.1).to(gpu)
+    for cus in (0, 192):
+        m.split_streams = 1
+        ref = m(x, cus=cus).last_hidden_state.clone()
+        for n in (2, 4):
+            m.split_streams = n
+            for _ in range(4):
+                got = m(x, cus=cus).last_hidden_state.clone()      # clone + drop: the pattern that exposed the lifetime bug
+                torch.cuda.synchronize()
+                assert torch.equal(got, ref), (cus, n)
+    m.split_streams = 2
+    xs = x.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(xs, cus=192).last_hidden_state
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+def test_pipelined_arrangements_are_bit_identical(gpu):
+    """capture_pipelined records the body as one graph per branch (sampler's branch, audio front, one graph per encoder
+    chain) on streams of the device's pool; whichever chain count is used - forced, or chosen by timing - a replay returns
+    bit for bit what the eager pass returns, and the choice is reported."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    pipe = SamplingPipeline(W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3), device=gpu,
+                            prec="mixed")
+    pcm, voxel, noise = (t.to(gpu) for t in _inputs(32, 555))
+    ref = pipe.run(pcm, voxel, noise)
+    torch.cuda.synchronize()
+    ref = {k: ref[k].clone() for k in ("predicted_exp", "predicted_jaw", "style_emb")}
+    paired = pipe.prior.paired
+    for chains in (1, 2, 4, None):
+        pipe.capture_pipelined(pcm, voxel, noise, arrangements=None if chains is None else [(chains, paired)])
+        for _ in range(3):
+            out = pipe.replay_pipelined()
+        torch.cuda.synchronize()
+        for k, r in ref.items():
+            assert torch.equal(out[k], r), (chains, k)
+        a = pipe.arrangement
+        assert a["paired_sampler"] == bool(paired) and (chains is None or a["encoder_chains"] == chains)
+        assert len(pipe.stream_choice["chains"]) == a["encoder_chains"] - 1
+        print(a, pipe.stream_choice["head"], pipe.stream_choice["chains"])
+    pipe.prior.pair_status()

@@ -494,3 +494,36 @@ def test_two_term_fp16_gemm_exact_against_rounded_weights(gpu, monkeypatch, tile
     err = (outs["1"].double() - ref).abs().max().item()
     assert err < 3e-5 * max(1.0, (K / 64) ** 0.5), err
     assert torch.equal(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("M,N,K", [(8000, 3072, 768), (2000, 768, 3072), (1000, 2304, 768), (333, 768, 1536)])
+@pytest.mark.parametrize("prec", [3, 2])
+def test_plane_gemm_result_does_not_depend_on_the_tile_shape(gpu, monkeypatch, M, N, K, prec):
+    """The dispatcher picks 256 x 256, 128 x 256 or 128 x 192 tiles from M, N and the CU budget (csrc/gemm.hip tile_score);
+    a projection must return the same bits whichever it picks - the same rows then come out the same in a full batch, a
+    sub-batch or one encoder chain of it (host/wav2vec._encoder_layers_split).  Same products in the same order in all three
+    kernels, and since this round the same GELU (the LDS table) in their epilogues: fp32 and plane outputs, GELU and
+    residual, 3-term bf16 and 2-term fp16."""
+    from avi_talking_amd import ops
+    x, w, b, r = _rand((M, K), 1), _rand((N, K), 2, K ** -0.5), _rand((N,), 3), _rand((M, N), 4)
+    pw = ops.PackedWeight(w.to(gpu), b.to(gpu))
+    fmt = ops.plane_fmt(prec)
+    xp = ops.Planes((M, K), gpu, fmt)
+    dt = torch.float16 if fmt == ops.PLANES_F16 else torch.bfloat16
+    hi = x.to(dt)
+    xp.hi.copy_(hi.view(torch.int16).to(gpu))
+    xp.lo.copy_((x - hi.float()).to(dt).view(torch.int16).to(gpu))
+    rg = r.to(gpu)
+    got = {}
+    for tile in ("4", "5", "6"):
+        monkeypatch.setenv("AVI_GEMM_KERNEL", tile)
+        a = ops.linear_planes(xp, pw, act=ops.ACT_GELU, prec=prec)
+        p = ops.linear_planes(xp, pw, act=ops.ACT_GELU, prec=prec, out_planes=True)
+        c = ops.linear_planes(xp, pw, residual=rg, prec=prec)
+        torch.cuda.synchronize()
+        got[tile] = (a.cpu(), p.hi.cpu(), p.lo.cpu(), c.cpu())
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double()))
+    assert (got["4"][0].double() - ref).abs().max().item() < {3: 3e-5, 2: 2e-3}[prec] * max(1.0, (K / 64) ** 0.5)
+    for tile in ("5", "6"):
+        for u, v in zip(got["4"], got[tile]):
+            assert torch.equal(u, v), tile
