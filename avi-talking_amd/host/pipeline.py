@@ -231,7 +231,7 @@ class SamplingPipeline:
             return self.prior.p_sample_loop((B, 1, 128), text_cond={"text_embed": clip_voxels.view(B, 1, 128)},
                                             cond_scale=1.0, timesteps=self.prior.noise_scheduler.num_timesteps, noise=nz)
 
-        def front():
+        def front():      # common to all chains: the CNN as two chains of clips measured slower (9.2 vs 8.7 ms, audio alone)
             return th.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B}, cus=cus, front_only=True)
 
         # every launch shape once outside a capture (kernel attributes such as LDS grants are set on first use)

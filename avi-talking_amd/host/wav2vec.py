@@ -101,6 +101,18 @@ class Wav2Vec2Model:
                                      w[p + "feed_forward.output_dense.bias"]),
                 ln2=(w[p + "final_layer_norm.weight"], w[p + "final_layer_norm.bias"])))
 
+        # the single fp16 weight plane of a 2-term group is derived from hi / lo on first use (ops.PackedWeight.f16_plane):
+        # build it HERE, on the constructing stream - the first use may otherwise come from one encoder chain's stream
+        # while another chain reads the half-built plane from its own
+        two_term = lambda p: (p & 0xff) == ops.PREC_F16X2
+        for pw in (self.convs if two_term(plan.conv) else []):
+            pw.f16_plane()
+        for ly in self.layers:
+            for pw in ((ly.qkv, ly.out) if two_term(plan.attn) else ()) + ((ly.ff1, ly.ff2) if two_term(plan.ffn) else ()):
+                pw.f16_plane()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
     @classmethod
     def from_state_dict(cls, state_dict, **kw):
         return cls(state_dict, **kw)

@@ -604,6 +604,11 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         return out
 
     marks = []
+    # The pass runs the 12 encoder layers as chains of clips on separate streams (host/wav2vec._encoder_layers_split): here
+    # the chains keep their launch shapes (M = clips per chain x T) but run one after the other on the launch stream, so
+    # that an event pair brackets ONE kernel beside the sampler and not two overlapping ones
+    am = pipe.talking_head.audio_model
+    chain_streams, am._split_streams = am._split_streams, [torch.cuda.current_stream(pipe.device)] * 8
     try:
         wrap("gemm_raw", gemm_work)
         wrap("attention_d64_planes", attn_work)
@@ -622,6 +627,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             setattr(ops, name, fn)
         prior.p_sample_loop = orig_sample
         prior.voxel2clip = orig_aligner
+        am._split_streams = chain_streams
     marks.append(len(rec))
     # every pass issues the same launches in the same order: a launch slot's duration is the MINIMUM over the kept
     # passes, so a host hiccup between recording e0 and enqueueing the kernel (eager mode) cannot inflate a family
@@ -670,9 +676,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             return v.get(field)
         return None
 
-    _B = voxel.shape[0]
-    _spg = max(1, min(prior.samples_per_group, _B)) if prior.samples_per_group > 0 else 1
-    sampler_cus = -(-_B // _spg)
+    sampler_cus = prior.cus_held(voxel.shape[0])
 
     def describe(name):
         ms, units, n, bound, ns = fam[name]
@@ -705,17 +709,21 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
         B = voxel.shape[0]
         sms = min(a.elapsed_time(b) for a, b in srec[1:])
         spg = max(1, min(prior.samples_per_group, B))
-        groups = -(-B // spg)
-        cus = groups * getattr(prior, "cus_per_group", 1)
+        paired = prior.uses_pairs(B)
+        groups = B if paired else -(-B // spg)
+        cus = prior.cus_held(B)
         plane_bytes = sum(t.numel() * t.element_size() for t in prior.net._packs)
         T = prior.noise_scheduler.num_timesteps
-        nbytes = plane_bytes * T * groups
+        # paired (csrc/prior_pair.hip): q heads and feed-forward halves split over the two CUs of a sample, each CU streams
+        # 524 KB of the 983 KB a layer's planes hold (k / v and the norms on both)
+        nbytes = int(plane_bytes * (524.0 / 983.0 if paired else 1.0)) * T * cus
         ams = min(a.elapsed_time(b) for a, b in arec[1:]) if len(arec) > 1 else 0.0
         entries.append({
             "bound": "hbm", "bound_detail": "weights re-streamed L2 -> CU every DDPM step (per-CU ingest, served by L2 / "
                                             "Infinity Cache: neither the HBM nor the MFMA roof); latency-bound chain of "
                                             f"{T} dependent steps",
-            "kernel": f"prior sampler ({T}-step DDPM in one launch, {groups} sample groups on {cus} CUs, side stream)",
+            "kernel": f"prior sampler ({T}-step DDPM in one launch, {groups} sample groups on {cus} CUs"
+                      f"{', two CUs per sample' if paired else ''}, side stream)",
             "achieved": round(nbytes / sms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(nbytes / sms / 1e6 / 8000.0, 4), "per_cu_gbps": round(nbytes / cus / sms / 1e6, 1),
             # what actually bounds it: a CU takes in 66-73 GB/s from its XCD's L2 (MI355X_MICROARCH.md, gather rates)

@@ -211,6 +211,14 @@ def test_encoder_chains_are_bit_identical(gpu):
                 got = m(x, cus=cus).last_hidden_state.clone()      # clone + drop: the pattern that exposed the lifetime bug
                 torch.cuda.synchronize()
                 assert torch.equal(got, ref), (cus, n)
+    # a 2-term plan's fp16 weight planes exist before the first pass: the very first call of a fresh model, chains first
+    # (the planes used to be derived on first use, i.e. on one chain's stream while the other chain already read them)
+    m2 = Wav2Vec2Model(W.make_wav2vec2_weights(0), device=gpu, prec="f16x2", length_mode="ceil")
+    m2.split_streams = 2
+    first = m2(x, cus=192).last_hidden_state.clone()
+    m2.split_streams = 1
+    assert torch.isfinite(first).all() and torch.equal(first, m2(x, cus=192).last_hidden_state)
+    del m2
     m.split_streams = 2
     xs = x.clone()
     g = torch.cuda.CUDAGraph()
