@@ -159,17 +159,21 @@ class SamplingPipeline:
 
     # ---- software-pipelined replay: the serial end of a pass runs beside its successor
     def capture_pipelined(self, pcm, voxel, noise=None, warmup=2, arrangements=None):
-        """Two graphs instead of one.  A pass ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms, the chip
-        almost idle) and begins with the aligner (0.19 ms of split-K launches that depend on the text feature alone).
-        Captured as `body` and `head` and replayed on two streams, the head of pass k runs beside the start of pass k+1;
-        inside `body` the aligner opens the sampler's branch, beside the audio front end (normalisation and conv layer 0,
-        0.5 ms without matrix-core work: its launches get CUs at once, and the sampler that follows it has 1.5 ms of slack
-        against the audio branch).  Back-to-back passes cost max(aligner + sampler, audio branch) each.  The hand-off goes
-        through private copies of the body's two results, guarded by events; every pass still does all of its work and
-        the results are bit-identical to `replay()` (tests/test_gpu_fullsize.py).
-        A separate aligner graph one pass ahead on a stream of its own was the first design: HIP multiplexes streams onto a
-        few in-order hardware queues, the aligner's stream shared the body's, and its launches ran BETWEEN two bodies
-        (0.19 ms per pass on the critical path, scripts/pass_timeline.py --gap)."""
+        """Body and head instead of one graph.  A pass ends with the EMOTE/FLINT head (~30 small dependent launches, 0.37 ms,
+        the chip almost idle); captured separately and replayed on a stream of its own it runs beside the start of pass
+        k+1.  The BODY is itself one graph per branch (`_capture_body`): the sampler's branch (noise draw, aligner, DDPM
+        loop) on the high-priority side stream, the audio front on the body's stream, the 12 encoder layers as one graph
+        per chain of clips on streams of the device's pool, joined by events (`_enqueue_body`).  Back-to-back passes cost
+        max(aligner + sampler, audio branch) each; the hand-off goes through private copies of the body's two results,
+        guarded by events; every pass still does all of its work and the results are bit-identical to `replay()`
+        (tests/test_gpu_fullsize.py).
+        ``arrangements``: [(encoder chains, paired sampler)] candidates; None = `_arrangements` (the chain count 2 vs 1 is
+        timed here, on this device, and the faster kept: `self.arrangement`).  Stream roles are timed once per device
+        (`_pick_streams`, `self.stream_choice`).
+        History: a separate aligner graph one pass ahead on a stream of its own was the first design - with the runtime's
+        default four hardware queues its stream shared the body's queue and its launches ran BETWEEN two bodies (0.19 ms
+        per pass on the critical path, scripts/pass_timeline.py --gap); one multi-branch body graph was the second (the
+        runtime chooses the branches' queues: see `_capture_body`)."""
         from .. import lib as L
         self._static = (pcm.clone(), voxel.clone(), None if noise is None else noise.clone())
         dev = self.device
