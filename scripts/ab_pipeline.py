@@ -17,10 +17,9 @@ wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_w
 B = 32
 pcm = bench.synth_audio(B, 160000, 1234).to(dev)
 voxel = torch.randn(B, 768, generator=torch.Generator().manual_seed(1235)).to(dev)
-configs = [dict(split=s, pair=p, all=a) for s, p, a in
-           ((1, 0, 0), (1, 1, 0), (2, 0, 0), (2, 1, 0), (4, 1, 0))]
+configs = [dict(split=s, pair=p) for s, p in ((1, 0), (1, 1), (2, 0), (2, 1), (4, 1))]
 if os.environ.get("AB_CONFIGS"):
-    configs = [dict(zip(("split", "pair", "all"), map(int, c.split(":")))) for c in os.environ["AB_CONFIGS"].split(",")]
+    configs = [dict(zip(("split", "pair"), map(int, c.split(":")))) for c in os.environ["AB_CONFIGS"].split(",")]
 pipes = []
 for c in configs:
     p = SamplingPipeline(wa, wh, wp, device=dev, prec=os.environ.get("AB_PREC", "mixed"), rng_seed=4242)

@@ -139,3 +139,49 @@ def test_precision_plans_resolve():
     assert ops.prec_plan(ops.PREC_F16X2).sampler_all_fp16 and not ops.prec_plan("mixed").sampler_all_fp16
     with pytest.raises(ValueError):
         ops.prec_plan("fp8")
+
+
+def test_pass_arrangement_rules(monkeypatch):
+    """Host logic of the sampling pass's arrangement (host/pipeline._arrangements, host/diffusion_prior.uses_pairs /
+    cus_held, the package's hardware-queue default): which candidates a capture times, which sampler kernel a batch gets
+    (a fixed rule: the two kernels differ by 1-3e-6, so timing must not choose), how many CUs the audio GEMMs tile for."""
+    from types import SimpleNamespace
+    import avi_talking_amd as pkg
+    from avi_talking_amd.host import pipeline as P
+    from avi_talking_amd.host.diffusion_prior import InstructDiffusionPrior as Prior
+
+    def prior(paired=True, spg=1, max_batch=32):
+        p = SimpleNamespace(paired=paired, samples_per_group=spg, pair_max_batch=max_batch)
+        p.uses_pairs = lambda B: Prior.uses_pairs(p, B)
+        p.cus_held = lambda B: Prior.cus_held(p, B)
+        return p
+
+    p = prior()
+    assert p.uses_pairs(1) and p.uses_pairs(32) and not p.uses_pairs(33)
+    assert p.cus_held(32) == 64 and p.cus_held(33) == 33 and p.cus_held(5) == 10
+    assert prior(paired=False).cus_held(32) == 32 and prior(paired=False, spg=5).cus_held(32) == 7
+    assert prior(spg=0).cus_held(32) == 32 and not prior(spg=0).uses_pairs(4)          # fp32 vector kernel: one CU per sample
+
+    def candidates(B, T, split_streams=2, hwq=8, env=None, paired=True):
+        monkeypatch.setattr(pkg, "HW_QUEUES", hwq)
+        if env is None:
+            monkeypatch.delenv("AVI_W2V_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("AVI_W2V_SPLIT", env)
+        me = SimpleNamespace(talking_head=SimpleNamespace(audio_model=SimpleNamespace(split_streams=split_streams)),
+                             prior=prior(paired))
+        return P.SamplingPipeline._arrangements(me, B, T)
+
+    assert candidates(32, 250) == [(2, True), (1, True)]               # timed: two chains against one, same sampler kernel
+    assert candidates(32, 250, paired=False) == [(2, False), (1, False)]
+    assert candidates(32, 250, hwq=4) == [(1, True)]                   # four queues: a second chain would share one
+    assert candidates(31, 250) == [(1, True)] and candidates(2, 25) == [(1, True)]     # odd batch / too few rows per chain
+    assert candidates(32, 250, split_streams=4, env="4") == [(4, True)]                # pinned by the environment
+    assert candidates(30, 250, split_streams=4, env="4") == [(1, True)]                # ... when the batch divides
+    assert candidates(32, 250, split_streams=1, env="1") == [(1, True)]
+
+    # the package's queue default: respects an explicit setting, does not touch the environment otherwise on import here
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    assert pkg._hw_queue_default() == 6
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "x")
+    assert pkg._hw_queue_default() == 4
