@@ -7,7 +7,9 @@ One "step" = one full pass of the path over one batch of synthetic input residen
 This is BASELINE.json configs[1] ("Single MI355X: batch 32 x 10 s clips, 25 fps FLAME coeffs,
 hipGraph-captured loop").  The DDPM loop runs the reference's actual 100 steps: a 50-step run is not a
 configuration the reference object supports.  The whole pass - the draw of the DDPM noise
-included (device-resident Philox stream, csrc/rng.hip) - is captured in hipGraphs and replayed per step.  Default
+included (device-resident Philox stream, csrc/rng.hip) - is captured in hipGraphs and replayed per step: one graph per
+branch (sampler's branch; audio front; the 12 encoder layers as two chains of 16 clips; the EMOTE/FLINT head beside the next
+pass), on streams picked by timing on the device (`config.arrangement`, `config.replay_streams` in the line).  Default
 precision plan: `mixed` (conv layers on 2 fp16 MFMAs per product, everything else on 3 bf16 MFMAs: 2.5e-4 on the
 coefficients, gate 3e-4, north_star 1e-3); `precision_modes` times the other plans, all-3-term `bf16x3` (2e-5)
 among them, in the same process.  Weights are seeded random-init of the reference architectures; data is
@@ -753,6 +755,11 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
     out = entries[0]
     out["others"] = entries[1:]
     out["audio_branch_ms_accounted"] = audio_ms
+    if am.split_streams > 1:
+        out["audio_branch_ms_accounted_note"] = (
+            f"sum of launches timed ONE AT A TIME beside the sampler; in the pass the 12 encoder layers run as "
+            f"{am.split_streams} chains of clips side by side (their launches - 128-row GEMMs, attention, LayerNorm - overlap), "
+            f"so the branch is shorter than this sum")
     out["pmc_sources"] = [x for x in (tsrc, bsrc) if x]
     return out
 
