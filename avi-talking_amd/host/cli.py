@@ -137,6 +137,7 @@ def run_test(args):
         name = os.path.basename(audio_path).split(".")[0]
         save_flame_pkl(os.path.join(folder, "flame", f"flame_{name}.pkl"), torch.zeros(300), out["predicted_exp"][0],
                        out["predicted_jaw"][0])
+        pipe.check()                             # the results were just read back: the pass is complete
         print(i, text, audio_path)
         print("{:04d} cost {:.3f} s, ave {:.3f} s".format(i, time.time() - t0, (time.time() - t0) / (i + 1)))
     return 0

@@ -135,6 +135,11 @@ class SamplingPipeline:
         out["style_emb"] = style
         return out
 
+    def check(self):
+        """After the caller has synchronised with the pass(es): raise if a paired-sampler launch gave up on its partner
+        (bounded spin in csrc/prior_pair.hip; the style of that pass is then garbage).  One tiny device read per batch size."""
+        self.prior.pair_status()
+
     # ---- hipGraph capture of the whole pass (static input buffers, replayed per batch)
     def capture(self, pcm, voxel, noise=None, warmup=2):
         self._static = (pcm.clone(), voxel.clone(), None if noise is None else noise.clone())

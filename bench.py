@@ -328,6 +328,12 @@ def main():
     torch.cuda.synchronize(dev)
     ref_out = {k: o_ref[k].clone() for k in ("predicted_exp", "predicted_jaw")}
     del o_ref
+    try:                         # after the synchronisations above: no paired-sampler launch gave up on its partner
+        pipe.check()
+        line["config"]["paired_sampler_status"] = "ok" if pipe.prior.uses_pairs(B_CLIPS) else "not used"
+    except RuntimeError as e:    # the line stays printable, but says that its passes are not valid
+        line["config"]["paired_sampler_status"] = f"FAILED: {e}"
+        line["error"] = str(e)
     line["config"]["replay_streams"] = getattr(pipe, "stream_choice", None)
     line["config"]["arrangement"] = getattr(pipe, "arrangement", None)      # encoder chains x sampler kernel, timed at capture
     del pipe, out
