@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                                                          const float* __restrict__ slopes, int period,
                                                          float* __restrict__ out, int ldo,
                                                          uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo,
-                                                         int out_fmt) {
+                                                         int out_fmt, unsigned* __restrict__ status) {
     constexpr int KS = D >= 32 ? D / 32 : 1;      // k-steps of the score product
     constexpr int DT = D / 16;                    // 16-dim tiles of the output
     constexpr int CH = D / 8;                     // 16-B chunks (8 dims) per image row
@@ -492,6 +492,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
         }
     }
     if (!active) return;
+    AviF16Range rng;                              // fp16 planes only: range guard (common.h)
+    const bool guard = out_hi && out_fmt == AVI_PLANES_F16;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
         if (q0 + qt * 16 + fr < Tq) {
@@ -507,6 +509,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         uint16_t h0, h1, l0, l1;
+                        if (guard) {
+                            rng.see(v[2 * j]);
+                            rng.see(v[2 * j + 1]);
+                        }
                         avi_split_hl(v[2 * j], out_fmt, h0, l0);
                         avi_split_hl(v[2 * j + 1], out_fmt, h1, l1);
                         hh[j] = h0 | ((uint32_t)h1 << 16);
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* __restrict
                 }
             }
         }
+    if (guard) rng.commit(status);
 }
 
 template <int D>
@@ -526,7 +533,7 @@ int launch_fused(const float* q, const float* k, const float* v, float* out, int
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(attn_fused_kernel<D>), FUSED_SMEM);
     hipLaunchKernelGGL(attn_fused_kernel<D>, dim3((Tq + FCH - 1) / FCH, B * H), dim3(512), FUSED_SMEM, s, q, k, v, Tq, Tk,
-                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo, out_fmt);
+                       H, ldq, ldk, scale, bias_mode, slopes, period, out, ldo, out_hi, out_lo, out_fmt, avi_status_ptr());
     return avi_launch_status();
 }
 

@@ -71,6 +71,34 @@ __device__ __forceinline__ void avi_split_hl(float v, int fmt, uint16_t& h, uint
     }
 }
 
+// ---- fp16-plane range guard (avi_talking.h "Status words").  A producer of AVI_PLANES_F16 planes feeds every value it
+// splits to see() (two vector instructions: and, max on the bit pattern - NaN > inf > finite as unsigned) and calls commit()
+// once per wave where the wave has reconverged: a wave-wide max, then at most two system-scope stores, and only when
+// something is wrong.  status == nullptr: commit() does nothing.
+unsigned* avi_status_ptr();                        // api.hip: the process-wide status word (host side)
+int avi_fault_injected();                          // api.hip: AVI_FAULT_* bits set by avi_debug_fault_inject
+struct AviF16Range {
+    unsigned m = 0;
+    __device__ __forceinline__ void see(float v) {
+        const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    __device__ __forceinline__ void commit(unsigned* __restrict__ status) {
+        if (!status) return;
+        unsigned w = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)w, o, 64);
+            w = other > w ? other : w;
+        }
+        if ((threadIdx.x & 63) != 0) return;
+        if (w >= 0x477FF000u)                          // 65520.0f: rounds to inf in fp16 (NaN / inf patterns are larger still)
+            __hip_atomic_store(status + AVI_STATUS_F16_OVERFLOW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (w != 0u && w < 0x39800000u)                // 2^-12
+            __hip_atomic_store(status + AVI_STATUS_F16_TINY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
 __device__ __forceinline__ float avi_gelu(float x) {
     // exact-form GELU: 0.5 x (1 + erf(x / sqrt(2)))  (torch.nn.functional.gelu, approximate='none'); |error| < 1e-6
     return 0.5f * x * (1.0f + avi_erf(x * 0.70710678118654752440f));

@@ -6,8 +6,13 @@
 namespace {
 
 // split-plane helpers: x = hi + lo (two bf16), 4 values at a time
-__device__ __forceinline__ void split4_store(uint16_t* hi, uint16_t* lo, long long o, const float v[4], int fmt) {
+__device__ __forceinline__ void split4_store(uint16_t* hi, uint16_t* lo, long long o, const float v[4], int fmt,
+                                             AviF16Range* rng = nullptr) {
     uint16_t h[4], l[4];
+    if (rng && fmt == AVI_PLANES_F16) {       // fp16 planes: range guard (common.h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rng->see(v[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) avi_split_hl(v[j], fmt, h[j], l[j]);
     *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
                                                            const float* __restrict__ w0,
                                                            const float* __restrict__ ss, float* __restrict__ y,
                                                            uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo,
-                                                           int fmt) {
+                                                           int fmt, unsigned* __restrict__ status) {
     __shared__ float sx[C0_TT * ST0 + K0 + 2];
     // 524 M outputs per step at ~37 vector instructions each made this kernel the vector pipe's (0.47-0.52 ms for 2.1 GB of
     // stores); GELU from the LDS table (gelu_table.h) is 12 of them fewer
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         sh[q] = ss[(long long)b * 2 * C0 + C0 + c];
     }
     __syncthreads();
+    AviF16Range rng;
     for (int tt = tsub; tt < C0_TT; tt += 2) {
         const int t = t0 + tt;
         if (t >= T0) break;
@@ -250,8 +256,9 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         }
         const long long off = ((long long)b * T0 + t) * C0 + cg * 4;
         if (y) *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
-        if (y_hi) split4_store(y_hi, y_lo, off, o, fmt);
+        if (y_hi) split4_store(y_hi, y_lo, off, o, fmt, &rng);
     }
+    if (y_hi && fmt == AVI_PLANES_F16) rng.commit(status);     // tsub is wave-uniform: the wave left the loop together
 }
 
 // ------------------------------------------------------------------ LayerNorm helpers (one wave per row)
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
                                                          const float* __restrict__ beta, float eps, int act,
                                                          const float* __restrict__ mask, const float* residual,
                                                          int stable, float* out, uint16_t* __restrict__ out_hi,
-                                                         uint16_t* __restrict__ out_lo, int fmt) {
+                                                         uint16_t* __restrict__ out_lo, int fmt,
+                                                         unsigned* __restrict__ status) {
     __shared__ float red[3][4];
     constexpr int LN = BR ? 256 : 64;
     const int row = BR ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6), lane = BR ? threadIdx.x : threadIdx.x & 63;
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
     }
     const float rstd = rsqrtf(rsum(q, 2) / C + eps);
     float* o = out ? out + (long long)row * C : nullptr;
+    AviF16Range rng;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + LN * i;
@@ -326,10 +335,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* in, int row
             if (o) reinterpret_cast<float4*>(o)[idx] = r;
             if (out_hi) {
                 const float rv[4] = {r.x, r.y, r.z, r.w};
-                split4_store(out_hi, out_lo, (long long)row * C + idx * 4, rv, fmt);
+                split4_store(out_hi, out_lo, (long long)row * C + idx * 4, rv, fmt, &rng);
             }
         }
     }
+    if (out_hi && fmt == AVI_PLANES_F16) rng.commit(status);   // a row belongs to whole waves: no lane has left
 }
 
 // ------------------------------------------------------------------ split-K epilogue (skinny GEMMs of the aligner MLP)
@@ -612,7 +622,7 @@ static int conv0_impl(const float* x, int B, int N, const float* w0, const float
     hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0 / 256, B), dim3(256), 0, s, moments, nchunks, w0, gamma, beta, T0,
                        eps, scale_shift);
     hipLaunchKernelGGL(conv0_apply_kernel, dim3((T0 + C0_TT - 1) / C0_TT, B), dim3(256), 0, s, x, N, T0, w0,
-                       scale_shift, y, y_hi, y_lo, fmt);
+                       scale_shift, y, y_hi, y_lo, fmt, avi_status_ptr());
     return avi_launch_status();
 }
 
@@ -658,10 +668,10 @@ extern "C" int avi_layernorm_ex(const float* in, int rows, int C, const float* g
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, rows, C, gamma, beta, eps, act, mask, residual,
-                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
+                           stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (unsigned*)nullptr);
     else   // a workgroup per row
         hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(rows), block, 0, s, in, rows, C, gamma, beta, eps, act, mask,
-                           residual, stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0);
+                           residual, stable, out, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (unsigned*)nullptr);
     return avi_launch_status();
 }
 
@@ -686,7 +696,7 @@ extern "C" int avi_layernorm_planes(const float* in, int rows, int C, const floa
     if (plane_fmt != AVI_PLANES_BF16 && plane_fmt != AVI_PLANES_F16) return AVI_EINVAL;
     hipLaunchKernelGGL(layernorm_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in,
                        rows, C, gamma, beta, eps, AVI_ACT_NONE, (const float*)nullptr, (const float*)nullptr, 0, out,
-                       out_hi, out_lo, plane_fmt);
+                       out_hi, out_lo, plane_fmt, avi_status_ptr());
     return avi_launch_status();
 }
 

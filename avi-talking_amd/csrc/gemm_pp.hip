@@ -79,7 +79,8 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 //   RAW  the real issues sit in exactly the slots, 5 phases ahead of the first read, that staged the even tiles before;
 //        the odd tile reads the same rows 4 phases later still.
 template <int NS, bool F16 = false, bool WS = false>
-__global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const int tilesM, const int tilesN) {
+__global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const int tilesM, const int tilesN,
+                                                       unsigned* __restrict__ status) {
     static_assert(!WS || (F16 && NS == 2), "weight super-tiles exist in the 2-term fp16 mode only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const int n = n0 + wc * 64 + ecol;
     float bv[8], sc[8], sh[8];
+    AviF16Range rng;                                    // fp16 planes only: range guard of what this wave splits
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool in = n + j < g.N;
@@ -483,6 +485,10 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         uint16_t h0, h1, l0, l1;
+                        if (F16) {
+                            rng.see(v[2 * j]);
+                            rng.see(v[2 * j + 1]);
+                        }
                         avi_split_hl(v[2 * j], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h0, l0);
                         avi_split_hl(v[2 * j + 1], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h1, l1);
                         h[j] = h0 | ((uint32_t)h1 << 16);
@@ -498,14 +504,17 @@ __global__ __launch_bounds__(NTHR) void gemm_pp_kernel(const AviGemm g, const in
                     if (n + j < g.N) {
                         const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
                         if (C) C[(long long)m * g.ldc + n + j] = y;
-                        if (Chi)
+                        if (Chi) {
+                            if (F16) rng.see(y);
                             avi_split_hl(y, F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, Chi[(long long)m * g.ldc + n + j],
                                          Clo[(long long)m * g.ldc + n + j]);
+                        }
                     }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the slab
     }
+    if (F16 && Chi) rng.commit(status);
 #ifdef AVI_PP_STAMPS
     if (stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -525,7 +534,7 @@ int launch(const AviGemm& g, hipStream_t s) {
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(gemm_pp_kernel<NS, F16, WS>), SMEM_BYTES);
     hipLaunchKernelGGL((gemm_pp_kernel<NS, F16, WS>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
-                       tilesN);
+                       tilesN, avi_status_ptr());
     return avi_launch_status();
 }
 

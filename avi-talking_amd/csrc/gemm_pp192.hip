@@ -73,7 +73,7 @@ constexpr int SK_MAXC = 4;     // contributors per tile the workspace has slots 
 template <int NS, int NT, bool F16 = false>
 __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const int tilesM, const int tilesN,
                                                           const int sk_total, float* __restrict__ sk_ws,
-                                                          int* __restrict__ sk_cnt) {
+                                                          int* __restrict__ sk_cnt, unsigned* __restrict__ status) {
     constexpr int BN = Geo<NT>::BN, STAGE_BYTES = Geo<NT>::STAGE_BYTES, EP_STRIDE = Geo<NT>::EP_STRIDE,
                   EP_SLAB = Geo<NT>::EP_SLAB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                         (!R || (((g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0))) &&
                         (!Chi || (((reinterpret_cast<uintptr_t>(Chi) | reinterpret_cast<uintptr_t>(Clo)) & 7) == 0));
     char* slab = smem + wave * EP_SLAB;
+    AviF16Range rng;                                    // fp16 planes only: range guard of what this wave splits
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -382,6 +383,10 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     uint16_t h0, h1, l0, l1;
+                    if (F16) {
+                        rng.see(v[2 * j]);
+                        rng.see(v[2 * j + 1]);
+                    }
                     avi_split_hl(v[2 * j], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h0, l0);
                     avi_split_hl(v[2 * j + 1], F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, h1, l1);
                     h[j] = h0 | ((uint32_t)h1 << 16);
@@ -397,12 +402,15 @@ __global__ __launch_bounds__(NTHR) void gemm_pp192_kernel(const AviGemm g, const
                 if (n + j < g.N) {
                     const float y = v[j] + (R ? R[(long long)m * g.ldr + n + j] : 0.f);
                     if (C) C[(long long)m * g.ldc + n + j] = y;
-                    if (Chi)
+                    if (Chi) {
+                        if (F16) rng.see(y);
                         avi_split_hl(y, F16 ? AVI_PLANES_F16 : AVI_PLANES_BF16, Chi[(long long)m * g.ldc + n + j],
                                      Clo[(long long)m * g.ldc + n + j]);
+                    }
                 }
         }
     }
+    if (F16 && Chi) rng.commit(status);
     if (!sk_total) break;
     bar();            // the slabs overlay the stages: every wave has read its slab before the next item's LDS-DMA lands
   }
@@ -447,11 +455,11 @@ int launch(const AviGemm& g, hipStream_t s) {
         float* ws = g.sk_ws;
         int* cnt = reinterpret_cast<int*>(ws + (long long)tilesM * tilesN * SK_MAXC * BM * BN);
         hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT, F16>), dim3(sk_wgs, 1), dim3(NTHR), SMEM_BYTES, s, g, tilesM, tilesN,
-                           tilesM * tilesN * (nk / 3), ws, cnt);
+                           tilesM * tilesN * (nk / 3), ws, cnt, avi_status_ptr());
         return avi_launch_status();
     }
     hipLaunchKernelGGL((gemm_pp192_kernel<NS, NT, F16>), dim3(tilesM * tilesN, g.batch), dim3(NTHR), SMEM_BYTES, s, g, tilesM,
-                       tilesN, 0, nullptr, nullptr);
+                       tilesN, 0, nullptr, nullptr, avi_status_ptr());
     return avi_launch_status();
 }
 

@@ -19,8 +19,9 @@
 //
 // The exchange (MI355X_MICROARCH.md, "handoff-1to1": data-tagged 8-byte granules, no flag, no fence): every value travels as
 // one naturally aligned {fp32 value, 32-bit tag} written by ONE relaxed agent-scope store (global_store_dwordx2 sc1: write-
-// through to L2) and polled with relaxed agent-scope loads (sc1: L1 bypassed).  tag = launch epoch << 12 | exchange number, so a
-// granule of an earlier exchange or an earlier launch never matches; two slots per half (exchange parity): a slot is rewritten
+// through to L2) and polled with relaxed agent-scope loads (sc1: L1 bypassed).  tag = launch epoch (16 bits) << 16 | exchange
+// number (16 bits; the entry point refuses loops with more than 65534 exchanges), so a granule of an earlier exchange or an
+// earlier launch never matches; two slots per half (exchange parity): a slot is rewritten
 // at exchange n + 2, which the writer can only reach after it has RECEIVED the partner's n + 1, which the partner sent after a
 // workgroup barrier behind its poll of n.  vmcnt is in order per WAVE, so a poll issued behind a prefetch would wait for the
 // prefetched weights: waves 4-7 poll (ring empty) while waves 0-3 issue the next matrix's prefetch and keep the CU's memory
@@ -115,13 +116,15 @@ struct Xch {
     unsigned long long* mine;          // [2 parities][XCH_VALS] granules this half writes
     const unsigned long long* theirs;  // the partner's
     unsigned long long* err;           // header word 1
-    unsigned epoch;                    // low 20 bits of the launch epoch
+    unsigned* status;                  // the process's status word (may be null)
+    unsigned epoch;                    // low 16 bits of the launch epoch
     unsigned seq;                      // exchanges done so far in this launch
+    bool dead;                         // this thread has given up on the partner: NaN from now on, no more spinning
 };
 
 // the partial sums s.y[0 .. R)[0 .. 128) out as granules (all threads)
 __device__ __forceinline__ void xch_send(const SmemS& s, int R, const Xch& x) {
-    const unsigned tag = (x.epoch << 12) | (x.seq + 1);
+    const unsigned tag = (x.epoch << 16) | (x.seq + 1);
     unsigned long long* dst = x.mine + (x.seq & 1) * XCH_VALS;
     for (int i = threadIdx.x; i < R * DIM; i += NT) {
         const float v = s.y[i >> 7][i & 127];
@@ -130,8 +133,8 @@ __device__ __forceinline__ void xch_send(const SmemS& s, int R, const Xch& x) {
     }
 }
 // waves 4-7: the partner's partial sums into registers (3 per lane); bounded spin
-__device__ __forceinline__ void xch_poll(int R, const Xch& x, float (&v)[3]) {
-    const unsigned tag = (x.epoch << 12) | (x.seq + 1);
+__device__ __forceinline__ void xch_poll(int R, Xch& x, float (&v)[3]) {
+    const unsigned tag = (x.epoch << 16) | (x.seq + 1);
     const unsigned long long* src = x.theirs + (x.seq & 1) * XCH_VALS;
     const int j = threadIdx.x - NT / 2;
 #pragma unroll
@@ -139,17 +142,20 @@ __device__ __forceinline__ void xch_poll(int R, const Xch& x, float (&v)[3]) {
         const int i = j + k * (NT / 2);
         v[k] = 0.f;
         if (i < R * DIM) {
-            unsigned long long gr = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long gr = x.dead ? 0ull : __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
-            while ((unsigned)(gr >> 32) != tag) {
+            while (!x.dead && (unsigned)(gr >> 32) != tag) {
                 if (++spins > SPIN_LIMIT) {
                     __hip_atomic_store(x.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (x.status)
+                        __hip_atomic_store(x.status + AVI_STATUS_PAIR_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    x.dead = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
                 gr = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            v[k] = __builtin_bit_cast(float, (unsigned)gr);
+            v[k] = x.dead ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)gr);
         }
     }
 }
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(NT, 2) void prior_sample_pair_kernel(const PriorArg
                                                                   const float* __restrict__ noise,
                                                                   const float* __restrict__ temb, int B, float inv_scale,
                                                                   float* __restrict__ out,
-                                                                  unsigned long long* __restrict__ xch_ws) {
+                                                                  unsigned long long* __restrict__ xch_ws,
+                                                                  unsigned* __restrict__ status, int fault) {
     const PriorArgs& a = kernarg();
     const AviPriorWeights& w = a.w;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -342,14 +349,17 @@ __global__ __launch_bounds__(NT, 2) void prior_sample_pair_kernel(const PriorArg
     const int pair = grp * 8 + (within & 7), hf = within >> 3;
     const int npairs = (B + PAIR_S - 1) / PAIR_S;
     if (pair >= npairs) return;                    // both halves of a pair that does not exist leave together
+    if (fault && hf == 1) return;                  // avi_debug_fault_inject: the partner that never answers
     const int b0 = pair * PAIR_S;
     const int Sg = min(PAIR_S, B - b0);
     Xch x;
     x.mine = xch_ws + XCH_HDR + ((long long)pair * 2 + hf) * 2 * XCH_VALS;
     x.theirs = xch_ws + XCH_HDR + ((long long)pair * 2 + (hf ^ 1)) * 2 * XCH_VALS;
     x.err = xch_ws + 1;
-    x.epoch = (unsigned)(__hip_atomic_load(xch_ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFu);
+    x.status = status;
+    x.epoch = (unsigned)(__hip_atomic_load(xch_ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu);
     x.seq = 0;
+    x.dead = false;
     for (int i = tid; i < MR * XPS; i += NT) (&s.xh[0][0])[i] = (&s.xl[0][0])[i] = 0;
     for (int i = tid; i < MR * DIM; i += NT) (&s.tok[0][0])[i] = 0.f;
     for (int i = tid; i < w.depth * 3 * DIM; i += NT) {
@@ -408,14 +418,14 @@ __global__ __launch_bounds__(NT, 2) void prior_sample_pair_kernel(const PriorArg
 #endif
 }
 
-// after the sampler, in stream order: the next launch's epoch; every 2^20 launches the tag space wraps, so the slots are
+// after the sampler, in stream order: the next launch's epoch; every 2^16 launches the tag space wraps, so the slots are
 // cleared (no granule of the previous cycle can match a new tag)
 __global__ void prior_pair_epoch_kernel(unsigned long long* __restrict__ ws, long long slot_words) {
     __shared__ int wrap;
     if (threadIdx.x == 0) {
         const unsigned long long e = ws[0] + 1;
         if (blockIdx.x == 0) ws[0] = e;
-        wrap = (e & 0xFFFFFull) == 0;
+        wrap = (e & 0xFFFFull) == 0;
     }
     __syncthreads();
     if (wrap)
@@ -434,7 +444,7 @@ int launch_pair(const AviPriorWeights* w, const AviPriorPlanes* p, const float* 
     const int npairs = (B + PAIR_S - 1) / PAIR_S;
     const int blocks = (npairs + 7) / 8 * 16;
     hipLaunchKernelGGL(prior_sample_pair_kernel<FF16>, dim3(blocks), dim3(NT), sizeof(SmemS), s, args, text_embed, noise, temb,
-                       B, inv_scale, out, ws);
+                       B, inv_scale, out, ws, avi_status_ptr(), avi_fault_injected() & AVI_FAULT_PAIR_PARTNER_ABSENT);
     // ONE block: the epoch word is read-modify-written once; the (rare) wrap clear is a loop of that block
     hipLaunchKernelGGL(prior_pair_epoch_kernel, dim3(1), dim3(256), 0, s, ws, (long long)npairs * 2 * 2 * XCH_VALS);
     return avi_launch_status();
@@ -450,14 +460,16 @@ extern "C" long long avi_prior_pair_workspace_bytes(int B) {
 
 // Paired sampler: same contract as avi_prior_sample_batched_tab (time table built by avi_prior_time_table) plus `workspace`:
 // avi_prior_pair_workspace_bytes(B) bytes of device memory, zero-filled ONCE by the caller and then left to the library (it
-// carries the launch epoch); one launch at a time may use it (stream order).  workspace[1] (u64) != 0 afterwards: a partner
-// never answered (bounded spin) and the result is invalid.
+// carries the launch epoch); one launch at a time may use it (stream order).  A partner that never answers (bounded spin)
+// turns the pair's outputs into NaN and raises workspace[1] (u64) and AVI_STATUS_PAIR_TIMEOUT (avi_talking.h).
 extern "C" int avi_prior_sample_paired(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed,
                                        const float* noise, int B, float inv_scale, float* out, const float* temb_table,
                                        void* workspace, void* stream) {
     if (!w || !p || !text_embed || !noise || !out || !temb_table || !workspace || B <= 0) return AVI_EINVAL;
     if (reinterpret_cast<uintptr_t>(workspace) & 7) return AVI_EINVAL;
     if (w->depth < 1 || w->depth > AVI_PRIOR_MAX_DEPTH || !p->proj_hi) return AVI_EINVAL;
+    // two exchanges per layer and step, numbered from 1 in 16 bits of the granule tag
+    if (w->timesteps < 1 || 2ll * w->depth * w->timesteps >= 65535) return AVI_EINVAL;
     const bool attn16 = p->proj_lo == nullptr, ff16 = p->layer[0].w1_lo == nullptr;
     if (attn16 && !ff16) return AVI_EINVAL;
     for (int l = 0; l < w->depth; ++l) {

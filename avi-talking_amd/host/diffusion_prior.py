@@ -277,6 +277,9 @@ class InstructDiffusionPrior:
         self.paired = os.environ.get("AVI_PRIOR_PAIR", "1") == "1" and net.ff_fp16 and not net.attn_fp16
         self.pair_max_batch = int(os.environ.get("AVI_PRIOR_PAIR_MAX_BATCH", "32"))
         self._pair_ws = {}
+        if self.device.type == "cuda":
+            from . import status
+            status.words()                 # a paired launch that gives up on its partner reports here (and returns NaN)
 
     @classmethod
     def from_state_dict(cls, state_dict, device="cuda", prec=ops.PREC_BF16X3, timesteps=100, attn_fp16=None):
@@ -290,15 +293,21 @@ class InstructDiffusionPrior:
     def cus_held(self, B):
         """Compute units the sampler's workgroups occupy from launch to the end of the loop (one workgroup per CU)."""
         if self.uses_pairs(B):
-            return 2 * B
+            return 2 * ((B + 1) // 2)      # a PAIR of samples on two workgroups (csrc/prior_pair.hip launch_pair)
         spg = self.samples_per_group
         return B if spg <= 0 else (B + min(spg, B) - 1) // min(spg, B)
 
     def pair_status(self):
-        """After a synchronisation: raises if a paired-sampler launch saw a partner that never answered (bounded spin)."""
-        for B, ws in self._pair_ws.items():
-            if int(ws[1].item()) != 0:
-                raise RuntimeError(f"paired sampler (B={B}): exchange timed out, results are invalid")
+        """Raises ``status.PairTimeout`` if a completed paired-sampler launch saw a partner that never answered (bounded
+        spin; that launch's style is NaN).  Reads the library's status words in pinned host memory: no synchronisation, no
+        device read.  The report is cleared - here and in the launch workspaces' own sticky word - so it raises once."""
+        from . import status
+        if status.read()[status.PAIR_TIMEOUT]:
+            for ws in self._pair_ws.values():
+                ws[1].zero_()
+            status.words()[status.PAIR_TIMEOUT] = 0
+            raise status.PairTimeout("paired DDPM sampler: a workgroup's partner never answered within the bounded spin; "
+                                     "the style of that pass is NaN (csrc/prior_pair.hip)")
 
     def time_table(self):
         """(T, 128) time embeddings of every timestep (models/diffusion_prior.py:188-191,284), built on first use."""

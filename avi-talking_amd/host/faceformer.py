@@ -61,9 +61,10 @@ def _pad_k(w2d, mult=64):
 
 
 class Faceformer:
-    def __init__(self, state_dict, audio_state_dict=None, period=30, device="cuda", prec=ops.PREC_BF16X3,
+    def __init__(self, state_dict, audio_state_dict=None, period=30, device="cuda", prec=None,
                  coeff_mean=None, coeff_std=None, max_seq_len=600):
         self.device = torch.device(device)
+        prec = ops.prec_plan(prec)                      # None = ops.DEFAULT_PREC (the audio encoder's plane-operand GEMMs)
         self.prec = ops.prec_plan(prec).small           # the decoder's own GEMMs are fp32-operand launches
         self.period = period
         self.max_seq_len = max_seq_len          # reference mask / PPE tables stop at 600 frames (:88,147)

@@ -19,6 +19,7 @@ import os
 import torch
 
 from .. import ops
+from . import status
 from .diffusion_prior import InstructDiffusionPrior
 from .talking_head import TalkingHeadWrapper
 
@@ -48,9 +49,11 @@ def device_streams(device):
 
 
 class SamplingPipeline:
-    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=ops.PREC_BF16X3, joint_norm=False, side_stream=None,
+    def __init__(self, audio_sd, head_sd, prior_sd, device="cuda", prec=None, joint_norm=False, side_stream=None,
                  rng_seed=None, out_dtype=torch.float32):
-        """``rng_seed``: draw the DDPM noise INSIDE the pass from the library's device-resident Philox stream (host/rng.py)
+        """``prec``: None = ``ops.DEFAULT_PREC`` ("mixed": the plan bench.py's headline is measured on), a plan name
+        ("bf16x3", "mixed", "mixed_ffn", "f16x2"), an AVI_PREC_* value or an ops.PrecPlan.
+        ``rng_seed``: draw the DDPM noise INSIDE the pass from the library's device-resident Philox stream (host/rng.py)
         whenever a call passes ``noise=None`` - the reference draws it inside its loop (models/diffusion_prior.py:337,
         349-351); a captured pass then draws fresh noise at every replay.  None = the caller supplies the noise tensor."""
         self.device = torch.device(device)
@@ -58,7 +61,11 @@ class SamplingPipeline:
         from .rng import DeviceRng
         self.rng = None if rng_seed is None else DeviceRng(rng_seed, self.device)
         self._noise_bufs = {}          # per batch size, never freed: captured graphs keep writing into theirs
-        self.plan = plan = ops.prec_plan(prec)       # AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan
+        self.plan = plan = ops.prec_plan(prec)
+        self._sds, self._joint_norm = (audio_sd, head_sd, prior_sd), joint_norm      # run_checked's fallback pipeline
+        self._fallback_pipe = None
+        self.last_fallback = None      # what run_checked had to do for its most recent batch (None: nothing)
+        status.words()                 # the device-side failure reports this object polls (host/status.py)
         self.talking_head = TalkingHeadWrapper(audio_sd, head_sd, device=device, prec=plan, joint_norm=joint_norm)
         # the uniform fp16 mode also stores the sampler's attention matrices as one fp16 plane (the mixed plans leave the
         # sampler as it is in the default mode)
@@ -129,16 +136,72 @@ class SamplingPipeline:
 
     def run(self, pcm, voxel, noise=None):
         """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside
-        the pass, ``rng_seed``) -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128))."""
+        the pass, ``rng_seed``) -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128)).
+        Asynchronous.  A device-side failure of an EARLIER pass (fp16 plane range, paired-sampler timeout: host/status.py)
+        raises here, at the start of the next one, without any synchronisation; ``run_checked`` is the synchronous form
+        that detects and repairs a failure of its own pass."""
+        self._poll()
         feat, style = self._body(pcm, voxel, noise)
         out = self.talking_head.head(feat, style, out_dtype=self.out_dtype)
         out["style_emb"] = style
         return out
 
-    def check(self):
-        """After the caller has synchronised with the pass(es): raise if a paired-sampler launch gave up on its partner
-        (bounded spin in csrc/prior_pair.hip; the style of that pass is then garbage).  One tiny device read per batch size."""
+    def _poll(self):
+        """Raise for whatever the device has reported so far (two reads of pinned host memory, no synchronisation)."""
         self.prior.pair_status()
+        status.raise_if_set()
+
+    def check(self):
+        """After the caller has synchronised with the pass(es): raise ``status.PairTimeout`` if a paired-sampler launch gave
+        up on its partner (that pass's style and coefficients are NaN) or ``status.RangeError`` if an fp16 activation plane
+        left its range.  No device read: the kernels write into pinned host memory.  Every entry point of this object polls
+        the same words on its way in, so a caller that never calls check() still gets the exception at its next call."""
+        self._poll()
+
+    def synchronize(self):
+        """Wait for every pass enqueued so far, then check()."""
+        torch.cuda.synchronize(self.device)
+        self.check()
+
+    def run_checked(self, pcm, voxel, noise=None):
+        """``run`` + a synchronisation + the safety net: the batch is RE-RUN when the device reported that its pass cannot be
+        trusted - on the unpaired sampler kernel after a paired-sampler timeout, on the ``ops.FALLBACK_PREC`` plan (bf16
+        planes: fp32's range) after an fp16-plane range report - with the same DDPM noise as the failed pass.  Returns valid
+        results or raises; ``self.last_fallback`` says what was done.  This is what host/cli.py calls per utterance."""
+        self.last_fallback = None
+        self._poll()
+        out = self.run(pcm, voxel, noise)
+        torch.cuda.synchronize(self.device)
+        ovf, tiny, pair = status.read()
+        if not (ovf or tiny or pair):
+            return out
+        if noise is None:                      # the failed pass drew its noise inside: the re-run takes the same numbers
+            noise = self._noise_buf.clone()
+        status.clear()
+        for ws in self.prior._pair_ws.values():
+            ws[1].zero_()
+        if ovf or tiny:
+            if self.plan.name == ops.FALLBACK_PREC:
+                raise status.RangeError("fp16-plane range report under the fallback plan itself (no fp16 planes there): "
+                                        "another object of this process is running a 2-term fp16 plan")
+            if self._fallback_pipe is None:
+                self._fallback_pipe = SamplingPipeline(*self._sds, device=self.device, prec=ops.FALLBACK_PREC,
+                                                       joint_norm=self._joint_norm, out_dtype=self.out_dtype)
+            self.last_fallback = (f"precision plan {ops.FALLBACK_PREC} (fp16 planes "
+                                  + ("overflowed" if ovf else "underflowed") + f" under {self.plan.name})")
+            out = self._fallback_pipe.run_checked(pcm, voxel, noise)
+            if self._fallback_pipe.last_fallback:
+                self.last_fallback += " + " + self._fallback_pipe.last_fallback
+            return out
+        was, self.prior.paired = self.prior.paired, False
+        try:
+            self.last_fallback = "unpaired sampler kernel (paired-sampler timeout)"
+            out = self.run(pcm, voxel, noise)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self.prior.paired = was
+        self._poll()                           # a failure of the re-run itself raises
+        return out
 
     # ---- hipGraph capture of the whole pass (static input buffers, replayed per batch)
     def capture(self, pcm, voxel, noise=None, warmup=2):
@@ -154,6 +217,7 @@ class SamplingPipeline:
     def replay(self, pcm=None, voxel=None, noise=None):
         if self._graph is None:
             raise RuntimeError("capture() first")
+        self._poll()
         for dst, src in zip(self._static, (pcm, voxel, noise)):
             if src is not None:
                 if dst is None:
@@ -273,24 +337,33 @@ class SamplingPipeline:
             were any.  It is launched first (its workgroups must get their CUs before a round of GEMM tiles does).
         Leaves `_e_body` recorded on A."""
         b, A, S = self._pbody, self._s_body, self.side
+        mark = self._mark
         if new_inputs:
             b.e_in.record(A)
         with torch.cuda.stream(S):
             if new_inputs:
                 S.wait_event(b.e_in)
             S.wait_event(self._e_taken)
+            mark("sampler_branch", 0, S)
             b.g_side.replay()
+            mark("sampler_branch", 1, S)
             b.e_side.record(S)
+        mark("audio_front", 0, A)
         b.g_front.replay()
+        mark("audio_front", 1, A)
         b.e_front.record(A)
         for i, C in enumerate(b.streams, 1):
             with torch.cuda.stream(C):
                 C.wait_event(b.e_front)
                 C.wait_event(self._e_taken)
+                mark(f"encoder_chain_{i}", 0, C)
                 b.g_chain[i].replay()
+                mark(f"encoder_chain_{i}", 1, C)
                 b.e_chain[i].record(C)
         A.wait_event(self._e_taken)
+        mark("encoder_chain_0", 0, A)
         b.g_chain[0].replay()
+        mark("encoder_chain_0", 1, A)
         for i in range(1, b.chains):
             A.wait_event(b.e_chain[i])
         A.wait_event(b.e_side)
@@ -380,6 +453,7 @@ class SamplingPipeline:
         ``pcm`` / ``voxel`` / ``noise``: the next batch, copied into the static input buffers on the body's stream in front
         of the replay (same contract as ``replay``; None = keep what the buffer holds).  The copy is ordered behind the
         previous body by the stream, so a caller may hand over batch k+1 while pass k is still running."""
+        self._poll()
         new_inputs = pcm is not None or voxel is not None or noise is not None
         if new_inputs:
             self._s_body.wait_stream(torch.cuda.current_stream(self.device))   # the caller's stream produced the new inputs
@@ -395,11 +469,53 @@ class SamplingPipeline:
             self._enqueue_body(new_inputs)
         with torch.cuda.stream(self._s_head):
             self._s_head.wait_event(self._e_body)
+            self._mark("head", 0, self._s_head)
             self._copy(self._pbody.feat, self._h_feat)
             self._copy(self._pbody.style, self._h_style)
             self._e_taken.record(self._s_head)
             self._g_head.replay()
+            self._mark("head", 1, self._s_head)
         return self._pout
+
+    # ---- where a replayed pass spends its time: timing events between the branch graphs of the ARRANGEMENT THAT RUNS
+    _marks = None
+
+    def _mark(self, name, end, stream):
+        if self._marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            self._marks[-1].setdefault(name, [None, None])[end] = e
+
+    def pass_timeline(self, passes=8, drop=2):
+        """Start / end of every branch graph of `replay_pipelined`, in ms from the start of the pass's audio front, measured
+        with timing events recorded on the branches' own streams between the graph replays of back-to-back passes - i.e.
+        in the arrangement the benchmark times, not launch by launch.  Returns {"branches": {name: {"start_ms", "end_ms",
+        "ms"}} (medians over the kept passes), "pass_ms": front start -> next front start, "bound_by": the branch that
+        ends last among those the next pass waits for}."""
+        import statistics
+        self._marks = []
+        try:
+            for _ in range(passes + 1):
+                self._marks.append({})
+                self.replay_pipelined()
+            torch.cuda.synchronize(self.device)
+            marks = self._marks
+        finally:
+            self._marks = None
+        rows, period = {}, []
+        for k in range(drop, passes):
+            t0 = marks[k]["audio_front"][0]
+            period.append(t0.elapsed_time(marks[k + 1]["audio_front"][0]))
+            for name, (a, b) in marks[k].items():
+                rows.setdefault(name, []).append((t0.elapsed_time(a), t0.elapsed_time(b)))
+        med = statistics.median
+        out = {name: {"start_ms": round(med(v[0] for v in vs), 3), "end_ms": round(med(v[1] for v in vs), 3),
+                      "ms": round(med(v[1] - v[0] for v in vs), 3)} for name, vs in sorted(rows.items())}
+        body = {n: r for n, r in out.items() if n != "head"}
+        return {"branches": out, "pass_ms": round(med(period), 3),
+                "bound_by": max(body, key=lambda n: body[n]["end_ms"]),
+                "note": "events on the branches' own streams between the graph replays of back-to-back pipelined passes; the "
+                        "head of pass k runs beside the front of pass k+1"}
 
     # ---- utterances of different lengths (the reference's loop takes them one at a time: train_diffusion_prior.py:689-771)
     def run_many(self, pcm_list, voxels, noises=None, generator=None, max_batch=32):
@@ -433,8 +549,9 @@ class SamplingPipeline:
                 sel = idx[k:k + max_batch]
                 pcm = torch.stack([pcm_list[i].reshape(-1)[:t * 640].to(self.device) for i in sel], 0).contiguous()
                 sel_t = torch.as_tensor(sel, device=noises.device)
-                res = self.run(pcm, voxels[sel].to(self.device).contiguous(),
-                               noises.index_select(1, sel_t).to(self.device).contiguous())
+                # synchronous per group, with the safety net (a failed pass is re-run, never returned)
+                res = self.run_checked(pcm, voxels[sel].to(self.device).contiguous(),
+                                       noises.index_select(1, sel_t).to(self.device).contiguous())
                 for j, i in enumerate(sel):
                     out[i] = {"predicted_exp": res["predicted_exp"][j], "predicted_jaw": res["predicted_jaw"][j],
                               "style_emb": res["style_emb"][j]}

@@ -1,0 +1,73 @@
+"""Device-side failure reports of the library (``include/avi_talking.h`` "Status words"), read WITHOUT a synchronisation.
+
+A launch can meet three failures that only the device sees: a value beyond the fp16 range written into an fp16 activation
+plane (the 2-term fp16 GEMM groups of the ``mixed`` / ``f16x2`` precision plans), an fp16 plane tile so small that its lo
+plane has gone subnormal, and a paired-sampler workgroup whose partner never answered.  The kernels store 1 into a word of
+PINNED HOST memory (plain system-scope stores); the host reads the words at the points it is at anyway - the start of
+the next pass, ``check()`` after the caller's own synchronisation - and raises.  The reference's counterpart is its
+host-side NaN sweep over the sample dict (inferno/utils/batch.py:22-34), five device synchronisations per forward.
+
+One block of words per process (the library drives one GPU per process).
+"""
+import torch
+
+from .. import lib as L
+
+F16_OVERFLOW, F16_TINY, PAIR_TIMEOUT, WORDS = 0, 1, 2, 4
+FAULT_PAIR_PARTNER_ABSENT = 1
+
+_words = None
+
+
+class RangeError(RuntimeError):
+    """An fp16 activation plane left the range in which the 2-term fp16 GEMM groups keep their accuracy."""
+
+
+class PairTimeout(RuntimeError):
+    """A paired-sampler workgroup gave up on its partner; that pass's style (and coefficients) are NaN."""
+
+
+def words():
+    """The process's status words (int32[WORDS], pinned host memory the device writes), registered with the library on
+    first use."""
+    global _words
+    if _words is None:
+        w = torch.zeros(WORDS, dtype=torch.int32).pin_memory()
+        L.check(L.load().avi_set_status_words(w.data_ptr()), "avi_set_status_words")
+        _words = w
+    return _words
+
+
+def read():
+    """(overflow, tiny, pair_timeout) as seen by the host NOW: no synchronisation, so a pass still in flight may not
+    have reported yet."""
+    w = words()
+    return bool(w[F16_OVERFLOW]), bool(w[F16_TINY]), bool(w[PAIR_TIMEOUT])
+
+
+def clear():
+    words().zero_()
+
+
+def raise_if_set(clear_after=True):
+    """Raise for whatever has been reported so far (PairTimeout before RangeError: its results are NaN).  The words are
+    cleared first, so one failure raises once and the object stays usable (``clear_after=False`` keeps them)."""
+    ovf, tiny, pair = read()
+    if not (ovf or tiny or pair):
+        return
+    if clear_after:
+        clear()
+    if pair:
+        raise PairTimeout("paired DDPM sampler: a workgroup's partner never answered within the bounded spin; the style of "
+                          "that pass is NaN (csrc/prior_pair.hip).  SamplingPipeline.run_checked() re-runs such a batch on "
+                          "the unpaired kernel; AVI_PRIOR_PAIR=0 never pairs")
+    what = []
+    if ovf:
+        what.append("a value beyond the fp16 range (|x| >= 65520 or non-finite) was written into an fp16 activation plane: "
+                    "the planes hold inf")
+    if tiny:
+        what.append("an fp16 activation plane tile was below 2^-12 everywhere: its lo plane is subnormal and the 2-term fp16 "
+                    "GEMM reading it is less accurate than its gate assumes")
+    raise RangeError("; ".join(what) + ".  The activations of this checkpoint / input do not fit the 2-term fp16 GEMM groups "
+                     "of the precision plan: use prec='bf16x3' (bf16 planes carry fp32's range), or "
+                     "SamplingPipeline.run_checked(), which falls back to it by itself")

@@ -182,8 +182,9 @@ class TalkingHeadWrapper:
     """Mirror of ``TalkingHeadWrapper.forward(sample, style_emb, only_style_emb, is_external_style_emb)``
     (TalkingHeadWrapper.py:123-138; patched FeedForwardDecoder.forward, FaceFormerDecoder.py:598-611)."""
 
-    def __init__(self, audio_state_dict, head_state_dict, device="cuda", prec=ops.PREC_BF16X3, joint_norm=True):
+    def __init__(self, audio_state_dict, head_state_dict, device="cuda", prec=None, joint_norm=True):
         self.device = torch.device(device)
+        prec = ops.prec_plan(prec)            # None = ops.DEFAULT_PREC
         # EMOTE's resampled wav2vec2 rounds the output length up (AudioEncoders.py:19-20)
         self.audio_model = Wav2Vec2Model(audio_state_dict, device=device, prec=prec, length_mode="ceil")
         self.head = EmoteHead(head_state_dict, device=device, prec=ops.fp32_operand_prec(prec))

@@ -895,6 +895,15 @@ class PriorTrainer:
             try:
                 begin()
                 self._gout = fb()
+            except BaseException:
+                # leave nothing half open: end the capture this thread is in (its graph is thrown away), forget the segments
+                # and the announcements made so far - the caller may fall back to the eager step on this object
+                try:
+                    cur["g"].capture_end()
+                except Exception:
+                    pass
+                self._segs, self.sync.done, self.sync.works = [], [], []
+                raise
             finally:
                 self._cut = None
         torch.cuda.current_stream(self.device).wait_stream(stream)

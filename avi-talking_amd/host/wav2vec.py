@@ -33,13 +33,16 @@ def conv_out_lengths(n):
 class Wav2Vec2Model:
     """wav2vec2-base with 50->25 Hz linear resampling between the CNN and the transformer."""
 
-    def __init__(self, state_dict, device="cuda", prec=ops.PREC_BF16X3, length_mode="int"):
+    def __init__(self, state_dict, device="cuda", prec=None, length_mode="int"):
         self.device = torch.device(device)
-        # prec: an AVI_PREC_* value, "mixed" / "mixed_ffn", or an ops.PrecPlan: one precision per group of plane-operand
+        # prec: None (= ops.DEFAULT_PREC), an AVI_PREC_* value, a plan name, or an ops.PrecPlan: one precision per group of plane-operand
         # GEMMs (conv layers 1-6 | q/k/v/out | ffn: 98 % of the FLOPs).  A 2-term fp16 group (PREC_F16X2) reads fp16 hi/lo
         # planes and one fp16 weight plane; the small fp32-operand GEMMs (feature projection, pos-conv) stay on the 3-term bf16 split
         self.plan = plan = ops.prec_plan(prec)
         self.prec = prec = plan.small
+        if self.device.type == "cuda" and ops.plan_uses_fp16_planes(plan):
+            from . import status
+            status.words()      # fp16 planes have a finite range: their producers report overflow / underflow here
         self.length_mode = length_mode          # "int": wav2vec.py:69-71; "ceil": AudioEncoders.py:19-20
         # Activation format.  Conv stack: bf16 hi/lo planes feeding the 256x256 ping-pong GEMM (gemm_pp.hip), each
         # layer's epilogue emitting the next layer's planes (AVI_W2V_PLANES=0: fp32 activations + gemm.hip).
@@ -194,8 +197,10 @@ class Wav2Vec2Model:
         FA, FF = ops.plane_fmt(PA), ops.plane_fmt(PF)
         # stream-K workspace of the 128-row GEMMs (csrc/gemm_pp192.hip): only when the caller says how many CUs are free -
         # M = 8000 on the 224 CUs beside the sampler leaves 16 % of the last round of qkv / out / ffn2 idle otherwise
+        # ONE workspace per model and its contract is one launch at a time: the chains of clips (_inner) run concurrently on
+        # their own streams and inside their own graph captures, so only the single-chain path may use it
         ws = None
-        if cus and self.stream_k:
+        if cus and self.stream_k and not _inner and self.split_streams <= 1:
             M = h.shape[0] * h.shape[1]
             if self._sk_ws is None or self._sk_ws[0] != M:
                 self._sk_ws = (M, ops.stream_k_workspace(M, 3 * HIDDEN, self.device))

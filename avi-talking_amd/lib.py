@@ -182,9 +182,13 @@ SIGNATURES = {
     "avi_mse_loss": [_vp, _vp, _i, _f, _vp, _vp, _vp],
     "avi_soft_clip_loss": [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "avi_adamw": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp],
+    "avi_set_status_words": [_vp],
+    "avi_status_words": [],                                  # returns void* (RESTYPES below)
+    "avi_debug_fault_inject": [_i],
+    "avi_debug_raise_status": [_i, _vp],
 }
 
-RESTYPES = {"avi_prior_pair_workspace_bytes": _ll}          # everything else returns an int status
+RESTYPES = {"avi_prior_pair_workspace_bytes": _ll, "avi_status_words": _vp}          # everything else returns an int status
 _lib = None
 
 

@@ -12,6 +12,16 @@ from .lib import (ACT_GELU, ACT_LRELU02, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT
                   PLANES_F16, PREC_BF16, PREC_BF16X3, PREC_F16X2)
 
 
+# THE default precision plan of every host class (SamplingPipeline, TalkingHeadWrapper, Wav2Vec2Model, Faceformer's audio
+# encoder), of host/cli.py (--prec) and of bench.py: the plan whose speed the headline reports is the plan a user of the
+# drop-in entry point gets.  "mixed": conv layers 1-6 on the 2-term fp16 GEMM, everything else 3-term bf16 - 1.9-2.5e-4
+# max-abs on the coefficients against the oracle and against the reference's own goldens (gate 3e-4; north_star 1e-3).
+# fp16 planes have a finite range: the plane producers report overflow / underflow (host/status.py) and
+# SamplingPipeline.run_checked falls back to "bf16x3" (2e-5, fp32's range) by itself.
+DEFAULT_PREC = "mixed"
+FALLBACK_PREC = "bf16x3"
+
+
 class PrecPlan:
     """Precision per GEMM group of the audio encoder.  One ``AVI_PREC_*`` value per group: ``conv`` = conv layers 1-6
     (half of the path's FLOPs), ``attn`` = q/k/v and out projections, ``ffn`` = the two feed-forward matrices; ``small`` =
@@ -32,6 +42,8 @@ def prec_plan(prec):
     """int ``PREC_*`` -> the uniform plan of that precision; "mixed" -> 2-term fp16 conv layers under 3-term bf16
     transformer projections (measured sensitivities of the coefficients to one fp16 weight plane: conv 2e-4, ffn 2.7e-4,
     q/k/v/out 5e-4); "mixed_ffn" -> conv and ffn 2-term, q/k/v/out 3-term; a PrecPlan passes through."""
+    if prec is None:
+        prec = DEFAULT_PREC
     if isinstance(prec, PrecPlan):
         return prec
     if isinstance(prec, str):
@@ -48,6 +60,12 @@ def prec_plan(prec):
     if base == PREC_F16X2:
         return PrecPlan("f16x2", prec, prec, prec, PREC_BF16X3, sampler_all_fp16=True)
     return PrecPlan({PREC_BF16X3: "bf16x3", PREC_BF16: "bf16"}.get(base, hex(prec)), prec, prec, prec, prec)
+
+
+def plan_uses_fp16_planes(plan):
+    """True when some GEMM group of the plan reads fp16 activation planes (whose range is finite: host/status.py)."""
+    plan = prec_plan(plan)
+    return any((p & 0xff) == PREC_F16X2 for p in (plan.conv, plan.attn, plan.ffn))
 
 
 def fp32_operand_prec(prec):

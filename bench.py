@@ -38,7 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-import avi_talking_amd  # noqa: E402,F401  before the first CUDA call: the package asks the runtime for 8 hardware queues
+import avi_talking_amd  # noqa: E402
+
+# before the first CUDA call: this program owns its process and asks the runtime for 8 hardware queues (an explicit opt-in;
+# the line records what it got under config.hw_queues)
+avi_talking_amd.request_hw_queues(8)
 
 B_CLIPS, SECONDS, FPS = 32, 10, 25
 N_SAMPLES = SECONDS * 16000
@@ -152,8 +156,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # 0.6 s of timed region: the clock settles within the first passes
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2", "mixed", "mixed_ffn"], default="mixed",
-                    help="mixed (default, headline) = conv layers 1-6 (half of the FLOPs) in 2-term fp16 (fp16 hi/lo activation "
+    ap.add_argument("--prec", choices=["bf16x3", "bf16", "f16x2", "mixed", "mixed_ffn"], default=None,
+                    help="default: ops.DEFAULT_PREC, the product's default plan (SamplingPipeline, host/cli.py).  mixed = conv layers 1-6 (half of the FLOPs) in 2-term fp16 (fp16 hi/lo activation "
                          "planes x one fp16 weight plane), transformer projections, heads and sampler in 3-term bf16: 2.5e-4 max-abs "
                          "on the coefficients vs the oracle on every tested config, gated at 3e-4 (north_star: 1e-3; the reference "
                          "itself runs fp16 autocast); bf16x3 = 3-term split bf16 everywhere (2e-5); mixed_ffn = conv and ffn 2-term "
@@ -217,6 +221,8 @@ def main():
     from avi_talking_amd import ops, weights as W
     from avi_talking_amd.host.pipeline import SamplingPipeline
 
+    if args.prec is None:
+        args.prec = ops.DEFAULT_PREC         # one default everywhere: the plan the product's classes and CLI use
     prec = ops.prec_plan(args.prec)
     wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
     # the DDPM noise of every timed pass is drawn INSIDE the pass (graph nodes, device-resident Philox stream), as the
@@ -273,19 +279,19 @@ def main():
                                "wav2vec2-base + BrainNetwork + 100-step DDPM prior + EMOTE/FLINT decoder",
                    "clips_per_gpu": B_CLIPS, "frames_per_clip": T_FRAMES, "ddpm_steps": 100,
                    "audio_normalisation": "joint over the batch" if args.joint_norm else "per clip",
-                   "hipgraph": not args.no_graph,
+                   "hipgraph": not args.no_graph, "precision_plan": repr(prec),
+                   "precision_plan_is_product_default": args.prec == ops.DEFAULT_PREC,
+                   "hw_queues": avi_talking_amd.HW_QUEUES,
                    "random_draws": "in the pass: (101,B,1,128) DDPM noise from the library's Philox-4x32-10 stream, drawn by "
                                    "nodes of the captured graph (fresh at every replay)",
                    "replay": "eager" if args.no_graph else "one graph per pass" if args.no_pipeline else
-                             "two graphs per pass (body, head) on two streams: the head of pass k runs beside the start of pass "
-                             "k+1, the aligner opens the sampler's branch beside the audio front end; every pass does all of its "
-                             "work, results bit-identical to the one-graph replay",
+                             "one graph per branch (sampler's branch, audio front, one per encoder chain, head) on streams of their "
+                             "own, tied by events: the head of pass k runs beside the start of pass k+1; every pass does all of "
+                             "its work, results bit-identical to the one-graph replay (roofline.branches has the timeline)",
                    "parallelism": f"dp{world} (independent utterances)"},
         "algorithmic_tflops": round(value * flops_per_frame(T_FRAMES) / 1e3, 1),
-        "max_abs_coeff_err_vs_oracle": {"mixed": "1.9e-4 - 2.5e-4 (tests/test_gpu_mixed_prec.py: configs[0], configs[1] sub-batch, "
-                                                 "T = 1500; gate 3e-4)", "bf16x3": "2e-5 (tests/test_gpu_emote.py)",
-                                        "north_star_gate": 1e-3}.get(args.prec, "see precision_modes") if args.prec in ("mixed", "bf16x3")
-        else "see precision_modes",
+        # MEASURED in this run (measure_parity below): the same pipeline object against the CPU oracle on one clip
+        "max_abs_coeff_err_vs_oracle": None, "parity": None,
         "roofline": None, "cpu_baseline": None, "precision_modes": None, "train": None, "faceformer": None, "longform": None, "flame": None,
         "clip_text": None,
     }
@@ -321,9 +327,14 @@ def main():
             line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if not args.no_roofline:
-        run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, line["ms_per_step"]))
+        run_leg("roofline", lambda: measure_roofline(pipe, pcm, voxel, noise, line["ms_per_step"],
+                                                     pipelined=not (args.no_graph or args.no_pipeline)))
+    oracle_case = {}
     if world == 1 and not args.no_cpu_baseline:
-        run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm))
+        run_leg("cpu_baseline", lambda: measure_cpu_baseline(wa, wh, wp, args.joint_norm, keep=oracle_case))
+    run_leg("parity", lambda: measure_parity(pipe, wa, wh, wp, dev, args.joint_norm, oracle_case))
+    if isinstance(line.get("parity"), dict) and "max_abs_coeff_err" in line["parity"]:
+        line["max_abs_coeff_err_vs_oracle"] = line["parity"]["max_abs_coeff_err"]
     o_ref = pipe.run(pcm, voxel, noise)                      # recorded noise: the reference point of the parity diffs
     torch.cuda.synchronize(dev)
     ref_out = {k: o_ref[k].clone() for k in ("predicted_exp", "predicted_jaw")}
@@ -524,7 +535,39 @@ def latest_profile(stem):
     return c[-1] if c else None
 
 
-def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
+def measure_parity(pipe, wa, wh, wp, dev, joint_norm, case):
+    """The second half of BASELINE's metric, measured in this run: max-abs difference of the un-normalised coefficients
+    between THIS pipeline object (the plan and kernels that were just timed) and the CPU oracle on the same (audio, text
+    feature, DDPM noise).  The clip is the one the cpu_baseline leg ran through the oracle (1 x 10 s; `case` holds its
+    inputs and the oracle's outputs); without that leg a 2 s clip goes through the oracle here."""
+    from oracle import emote as OE, prior as OP, wav2vec2 as OW
+    if not case:
+        T = 50
+        case["pcm"] = synth_audio(1, T * 640, 99)
+        case["voxel"] = torch.randn(1, 768, generator=torch.Generator().manual_seed(98))
+        case["noise"] = torch.randn(101, 1, 1, 128, generator=torch.Generator().manual_seed(97))
+        with torch.no_grad():
+            feat = OW.forward(wa, OW.normalize_audio(case["pcm"], joint=joint_norm), frame_num=T)
+            te, _ = OP.brain_network(wp, case["voxel"])
+            case["style"] = OP.p_sample_loop(wp, te.view(1, 1, 128), case["noise"])
+            case["ref"] = OE.forward(wh, feat, case["style"])
+    pcm = case["pcm"]
+    out = pipe.run(pcm.to(dev), case["voxel"].to(dev), case["noise"].to(dev))
+    torch.cuda.synchronize(dev)
+    pipe.check()
+    ref = case["ref"]
+    e_exp = (out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item()
+    e_jaw = (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item()
+    e_style = (out["style_emb"].cpu() - case["style"]).abs().max().item()
+    gate = {"mixed": 3e-4, "bf16x3": 5e-5}.get(pipe.plan.name, 1e-3)
+    return {"max_abs_coeff_err": float("%.3e" % max(e_exp, e_jaw)), "exp": float("%.3e" % e_exp), "jaw": float("%.3e" % e_jaw),
+            "style_emb": float("%.3e" % e_style), "plan": pipe.plan.name, "plan_gate": gate, "north_star_gate": 1e-3,
+            "within_plan_gate": max(e_exp, e_jaw) < gate,
+            "case": f"1 clip x {pcm.shape[1] / 16000:g} s (seed 99), 100-step DDPM with recorded noise, HIP pipeline vs the fp32 CPU "
+                    f"oracle, un-normalised expression(50) + jaw(3) coefficients"}
+
+
+def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
     """Per-launch HIP-event timing, on the stream each kernel is launched on, of the kernels that make up the step:
     every GEMM launch, the other launches of the audio branch that take >= 2 % of the step (conv layer 0, positional conv,
     encoder attention, LayerNorm; launch stream) and the one-launch DDPM sampler (side stream, concurrent with the audio
@@ -730,8 +773,8 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             "bound": "hbm", "bound_detail": "weights re-streamed L2 -> CU every DDPM step (per-CU ingest, served by L2 / "
                                             "Infinity Cache: neither the HBM nor the MFMA roof); latency-bound chain of "
                                             f"{T} dependent steps",
-            "kernel": f"prior sampler ({T}-step DDPM in one launch, {groups} sample groups on {cus} CUs"
-                      f"{', two CUs per sample' if paired else ''}, side stream)",
+            "kernel": f"prior sampler ({T}-step DDPM in one launch, {B} samples on {cus} CUs"
+                      f"{', a PAIR of samples on two CUs, each streaming half of every matrix' if paired else ''}, side stream)",
             "achieved": round(nbytes / sms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(nbytes / sms / 1e6 / 8000.0, 4), "per_cu_gbps": round(nbytes / cus / sms / 1e6, 1),
             # what actually bounds it: a CU takes in 66-73 GB/s from its XCD's L2 (MI355X_MICROARCH.md, gather rates)
@@ -767,10 +810,13 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3):
             f"{am.split_streams} chains of clips side by side (their launches - 128-row GEMMs, attention, LayerNorm - overlap), "
             f"so the branch is shorter than this sum")
     out["pmc_sources"] = [x for x in (tsrc, bsrc) if x]
+    if pipelined:
+        # the arrangement that was TIMED: start / end of every branch graph inside back-to-back replayed passes
+        out["branches"] = pipe.pass_timeline()
     return out
 
 
-def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16):
+def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16, keep=None):
     """the CPU oracle (fp32 torch restatement of the reference - a port; the reference import
     cannot travel to this box) on a BOUNDED sample, units B1-B5 timed separately, 1 warm-up + `reps` timed repetitions,
     median.  `value` = frames/s of the same path as the headline (B1 audio encoder + B3 prior + B2 head on one
@@ -807,6 +853,9 @@ def measure_cpu_baseline(wa, wh, wp, joint_norm=False, reps=5, threads=16):
 
         t1, t3 = med(b1), med(b3)
         t2 = med(lambda: OE.forward(wh, st["feat"], st["style"]))
+        if keep is not None:      # the clip and the oracle's results: measure_parity runs the GPU pipeline on the same inputs
+            with torch.no_grad():
+                keep.update(pcm=pcm, voxel=voxel, noise=noise, style=st["style"], ref=OE.forward(wh, st["feat"], st["style"]))
         units = {"B1_wav2vec2_1x10s_s": round(t1, 4), "B2_emote_flint_head_1x250_s": round(t2, 4),
                  "B3_aligner_plus_100step_ddpm_1_sample_s": round(t3, 4)}
         # B4: FaceFormer AR loop, hidden (1,T,D), as written (whole prefix re-decoded every frame) and KV-cached

@@ -51,6 +51,38 @@ extern "C" {
 const char* avi_version(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Status words: failures a launch can only find out about on the device.  `words` points to AVI_STATUS_WORDS 32-bit
+ * words; a later launch of this process that meets failure k STORES 1 into words[k] (a plain system-scope store, no
+ * read-modify-write: the words may live in pinned, device-mapped host memory and be read by the host WITHOUT a
+ * synchronisation; a platform without PCIe atomics is fine).  NULL (the initial state) switches the reporting off.  The
+ * library never clears a word; the owner does.  Nothing like it exists in the reference, whose guards are host-side NaN
+ * sweeps (inferno/utils/batch.py:22-34, train_diffusion_prior.py:135-137).
+ *   words[AVI_STATUS_F16_OVERFLOW]  a value written into an fp16 hi plane (AVI_PLANES_F16 producers: conv layer 0, the
+ *                                   plane-operand GEMM epilogues, LayerNorm, attention) was non-finite or beyond the fp16
+ *                                   range (|x| >= 65520): the planes hold inf, results are invalid.  bf16 planes have
+ *                                   fp32's range and are not guarded.
+ *   words[AVI_STATUS_F16_TINY]      a wave's whole share of an fp16 plane tile was below 2^-12 in magnitude (and not all
+ *                                   zero): the lo plane has gone subnormal and x = hi + lo no longer carries ~22 bits - the
+ *                                   2-term fp16 GEMM that consumes the planes is then less accurate than its weight
+ *                                   rounding (2^-12).
+ *   words[AVI_STATUS_PAIR_TIMEOUT]  a paired-sampler workgroup gave up on its partner (bounded spin,
+ *                                   avi_prior_sample_paired); that launch's output is NaN.
+ */
+#define AVI_STATUS_F16_OVERFLOW 0
+#define AVI_STATUS_F16_TINY 1
+#define AVI_STATUS_PAIR_TIMEOUT 2
+#define AVI_STATUS_WORDS 4
+int avi_set_status_words(void* words);
+void* avi_status_words(void);
+/* Diagnostics, so that the failure paths above can be tested.
+ * avi_debug_fault_inject: make later launches fail in a chosen way (0 = none):
+ *   AVI_FAULT_PAIR_PARTNER_ABSENT   the second workgroup of every sample pair of avi_prior_sample_paired leaves at once.
+ * avi_debug_raise_status: one launch on `stream` that stores 1 into words[k] the way a failing kernel would. */
+#define AVI_FAULT_PAIR_PARTNER_ABSENT 1
+int avi_debug_fault_inject(int faults);
+int avi_debug_raise_status(int k, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Batched strided GEMM with fused epilogue -- the dense contraction under every Linear / Conv1d
  * on the path:
  *     C[z][m][n] = affine( act( sum_k A[z][m*lda + k] * W[z][n][k] + bias[z][n] ) ) + R[z][m][n]
@@ -286,8 +318,11 @@ int avi_prior_sample_batched_tab(const AviPriorWeights* w, const AviPriorPlanes*
  * granules), because the loop above is bound by what ONE CU can take in from L2.  Same contract as
  * avi_prior_sample_batched_tab; plane formats: feed-forward matrices one fp16 plane, attention matrices bf16 hi / lo (the
  * default).  workspace: avi_prior_pair_workspace_bytes(B) bytes, zero-filled ONCE by the caller, then owned by the library
- * (launch epoch, exchange slots); one launch at a time (stream order).  After the launch has completed, workspace word 1
- * (u64) != 0 means a partner never answered within the bounded spin: the result is invalid. */
+ * (launch epoch, exchange slots); one launch at a time (stream order).  A partner that never answers within the bounded
+ * spin makes the launch FAIL LOUDLY: the half that gave up sends NaN from then on, so every output of the pair is NaN, and
+ * AVI_STATUS_PAIR_TIMEOUT is raised in the status word (avi_set_status_words) and in workspace word 1 (u64, sticky until the
+ * owner clears it).  An exchange is tagged with 16 bits of the launch epoch and a 16-bit exchange number:
+ * 2 * depth * timesteps must stay below 65536 (AVI_EINVAL otherwise). */
 long long avi_prior_pair_workspace_bytes(int B);
 int avi_prior_sample_paired(const AviPriorWeights* w, const AviPriorPlanes* p, const float* text_embed, const float* noise,
                             int B, float inv_scale, float* out, const float* temb_table, void* workspace, void* stream);

@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import avi_talking_amd as pkg
+pkg.request_hw_queues(8)
 from avi_talking_amd import weights as W
 from avi_talking_amd.host.pipeline import SamplingPipeline
 import bench

@@ -8,7 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-import avi_talking_amd  # noqa: E402,F401  before any test touches the GPU: the package sets the runtime's hardware-queue count
+import avi_talking_amd  # noqa: E402
+
+avi_talking_amd.request_hw_queues(8)     # before any test touches the GPU (explicit: importing the package changes nothing)
 
 
 def pytest_configure(config):

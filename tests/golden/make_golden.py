@@ -20,6 +20,8 @@ What is pinned:
   * flame.npz        inferno ``utils/lbs.py`` ``lbs`` (imported as is: pure torch) on the synthetic FLAME basis of
                      avi_talking_amd.weights.make_flame_basis, with the pose assembly of ``FLAME.forward``
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
+  * fixture_chain.npz the fixture WAV (and two seeded clips) through the reference's wav2vec2 wrapper AND its EMOTE head +
+                     FLINT decoder: audio -> coefficients on the reference's own modules (gen_fixture_chain).
   * emote.npz        inferno ``LinearSequenceEncoder`` (SequenceEncoders.py:180-197), ``LinearEmotionCondition``
                      (FaceFormerDecoder.py:186-268), ``BertPriorDecoder.forward`` -> ``FeedForwardDecoder.forward/_style``,
                      ``_decode``, ``_post_prediction`` -> ``_apply_motion_prior`` (:598-682,1104-1224) with
@@ -472,6 +474,39 @@ def gen_emote():
     print("emote.npz:", {k: v.shape for k, v in out.items()})
 
 
+def gen_fixture_chain():
+    """The reference's one real input end to end, through the reference's OWN modules: fixture WAV (channel 0, whole
+    640-sample frames, per-clip normalised) -> ``models/lib/wav2vec.py`` Wav2Vec2Model (frame_num = T, the call of
+    models/faceformer.py:330,673) -> last_hidden_state -> LinearSequenceEncoder -> BertPriorDecoder (external style, the
+    call of evaluation_functions.py:381) -> FLINT L2lDecoder -> predicted_exp / predicted_jaw.  A second case: two seeded
+    2 s clips.  Pins the audio -> coefficient chain of every precision plan on the reference itself (no oracle)."""
+    from transformers import Wav2Vec2Config
+    ref = load_by_path("ref_wav2vec", os.path.join(REF, "models/lib/wav2vec.py"))
+    model = ref.Wav2Vec2Model(Wav2Vec2Config(attn_implementation="eager")).eval()
+    print(model.load_state_dict(W.make_wav2vec2_weights(0), strict=True))
+    root = build_reference_emote()
+    out = {}
+    pcm = read_wav_ch0(os.path.join(REF, "experiments/wav_dir/0001/M012_front_neutral_level1_017.wav"))
+    T = len(pcm) // 640
+    fix = torch.from_numpy(pcm[:T * 640].astype(np.float32))[None]
+    g = torch.Generator().manual_seed(77)
+    rnd = (torch.randn(2, 50 * 640, generator=g) * 3000).round().clamp(-32768, 32767)       # int16-valued, like raw_audio
+    for tag, x in (("fixture", fix), ("randn2", rnd)):
+        B, T = x.shape[0], x.shape[1] // 640
+        xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-7)
+        style = torch.randn(B, 1, 128, generator=g) * 0.5
+        with torch.no_grad():
+            feat = model(xn, "vocaset", frame_num=T).last_hidden_state
+        s = run_reference_emote(root, feat, style)
+        assert s["predicted_exp"].shape == (B, T, 50)
+        out[f"{tag}_pcm"] = x.numpy().astype(np.int16)
+        out[f"{tag}_style"] = style.numpy()
+        out[f"{tag}_hidden_slice"] = feat[:, ::5, ::16].numpy()
+        out[f"{tag}_exp"], out[f"{tag}_jaw"] = s["predicted_exp"].numpy(), s["predicted_jaw"].numpy()
+        print(tag, tuple(feat.shape), float(s["predicted_exp"].abs().max()), float(s["predicted_jaw"].abs().max()))
+    np.savez_compressed(os.path.join(HERE, "fixture_chain.npz"), **out)
+
+
 def gen_clip_text():
     """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
     openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
@@ -499,8 +534,8 @@ def gen_clip_text():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote"):      # regenerate only one fixture
-        {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain"):      # regenerate only one fixture
+        {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote, "fixture_chain": gen_fixture_chain}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "faceformer_tf":
         gen_faceformer_teacher_forced(import_reference_models()[0])
@@ -509,6 +544,7 @@ if __name__ == "__main__":
     gen_clip_text()
     gen_wav2vec2()
     gen_emote()
+    gen_fixture_chain()
     ff, dp = import_reference_models()
     gen_masks(ff)
     gen_brain(dp)

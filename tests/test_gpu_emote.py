@@ -151,7 +151,8 @@ def test_ragged_and_empty_utterances(gpu):
         pipe.run_many(pcms, voxels[:2], noises)
 
 
-def test_config0_single_4s_clip_and_fixture_wav(gpu):
+@pytest.mark.parametrize("plan", ["mixed", "bf16x3"])
+def test_config0_single_4s_clip_and_fixture_wav(gpu, plan):
     """BASELINE.json configs[0]: one 4 s clip (64 000 samples -> 100 frames) through the whole sampling path with the
     reference's 100-step DDPM loop, and the reference's own fixture WAV (experiments/wav_dir/0001, channel 0, 79 872
     samples -> 124 frames, framed by host/audio_io.process_audio): HIP against the CPU oracle, 1e-3 max-abs on the
@@ -163,7 +164,8 @@ def test_config0_single_4s_clip_and_fixture_wav(gpu):
     from avi_talking_amd.host.pipeline import SamplingPipeline
     from oracle import emote as OE, prior as OP, wav2vec2 as OW
     wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
-    pipe = SamplingPipeline(wa, wh, wp, device=gpu)
+    gate = {"mixed": 3e-4, "bf16x3": 5e-5}[plan]         # the plan's own gate; north_star asks for 1e-3
+    pipe = SamplingPipeline(wa, wh, wp, device=gpu, prec=plan)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(1, 64000, generator=g)
     X = torch.fft.rfft(x)
@@ -182,5 +184,6 @@ def test_config0_single_4s_clip_and_fixture_wav(gpu):
         ref = OE.forward(wh, feat, OP.p_sample_loop(wp, te.view(1, 1, 128), noise))
         e = max((out["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
                 (out["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
-        print(f"{name}: T = {T}, max-abs coefficient err {e:.2e}")
-        assert out["predicted_exp"].shape == (1, T, 50) and e < 1e-3
+        print(f"{name} [{plan}]: T = {T}, max-abs coefficient err {e:.2e} (gate {gate:.0e})")
+        assert out["predicted_exp"].shape == (1, T, 50) and e < gate
+    pipe.synchronize()                                   # no device-side failure report (host/status.py)

@@ -158,7 +158,8 @@ def test_pass_arrangement_rules(monkeypatch):
 
     p = prior()
     assert p.uses_pairs(1) and p.uses_pairs(32) and not p.uses_pairs(33)
-    assert p.cus_held(32) == 64 and p.cus_held(33) == 33 and p.cus_held(5) == 10
+    # a PAIR of samples shares two workgroups (csrc/prior_pair.hip launch_pair: 2 * ceil(B / 2) of them do work)
+    assert p.cus_held(32) == 32 and p.cus_held(33) == 33 and p.cus_held(5) == 6 and p.cus_held(1) == 2
     assert prior(paired=False).cus_held(32) == 32 and prior(paired=False, spg=5).cus_held(32) == 7
     assert prior(spg=0).cus_held(32) == 32 and not prior(spg=0).uses_pairs(4)          # fp32 vector kernel: one CU per sample
 
@@ -185,3 +186,24 @@ def test_pass_arrangement_rules(monkeypatch):
     assert pkg._hw_queue_default() == 6
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "x")
     assert pkg._hw_queue_default() == 4
+    # the opt-in: an explicit setting wins; importing the package never writes the variable
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    assert pkg.request_hw_queues(8) == 6 and os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import avi_talking_amd as p; "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ and p.HW_QUEUES == 4; "
+            "assert p.request_hw_queues(8) == 8 and os.environ['GPU_MAX_HW_QUEUES'] == '8'" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True).returncode == 0
+
+
+def test_default_plan_is_the_benchmarked_plan():
+    """One default everywhere: the host classes, the CLI and bench.py resolve `None` to ops.DEFAULT_PREC."""
+    import inspect
+    from avi_talking_amd import ops
+    from avi_talking_amd.host import cli, faceformer, pipeline, talking_head, wav2vec
+    assert ops.DEFAULT_PREC == "mixed" and ops.prec_plan(None).name == "mixed"
+    for fn in (pipeline.SamplingPipeline.__init__, talking_head.TalkingHeadWrapper.__init__, wav2vec.Wav2Vec2Model.__init__,
+               faceformer.Faceformer.__init__):
+        assert inspect.signature(fn).parameters["prec"].default is None
+    assert cli.build_parser().parse_args([]).prec is None
