@@ -2,7 +2,8 @@
 //
 //   gelu(x) = max(x, 0) + e(|x|),   e(u) = -u Phi(-u): smooth, even in x, < 7e-9 beyond u = 6
 //
-// e is tabulated as one cubic per segment of [0, 6) (128 segments, 2 KiB; 2.4e-7 against float64 = fp32 rounding):
+// e is tabulated as one cubic per segment of [0, 6) (128 segments, 2 KiB; 2.4e-7 against float64 = fp32 rounding; the first
+// segment passes through the origin exactly, so tiny inputs keep their RELATIVE accuracy, gelu(x) -> x / 2 to 5e-7):
 // 10 vector instructions + one 16-byte LDS gather per value, against 22 for the rational erf of common.h.  Kernels whose
 // time is the vector pipe's (128 outputs per lane in the 256 x 256 GEMM's epilogue; conv layer 0, 524 M outputs at ~37
 // instructions each) copy the table into LDS once per workgroup and call avi_gelu_lds.

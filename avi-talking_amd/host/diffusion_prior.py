@@ -305,7 +305,7 @@ class InstructDiffusionPrior:
         if status.read()[status.PAIR_TIMEOUT]:
             for ws in self._pair_ws.values():
                 ws[1].zero_()
-            status.words()[status.PAIR_TIMEOUT] = 0
+            status.clear_word(status.PAIR_TIMEOUT)
             raise status.PairTimeout("paired DDPM sampler: a workgroup's partner never answered within the bounded spin; "
                                      "the style of that pass is NaN (csrc/prior_pair.hip)")
 

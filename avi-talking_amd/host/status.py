@@ -17,6 +17,7 @@ F16_OVERFLOW, F16_TINY, PAIR_TIMEOUT, WORDS = 0, 1, 2, 4
 FAULT_PAIR_PARTNER_ABSENT = 1
 
 _words = None
+_view = None       # numpy view of the same pinned memory: reading it dispatches no torch operator at all
 
 
 class RangeError(RuntimeError):
@@ -30,23 +31,29 @@ class PairTimeout(RuntimeError):
 def words():
     """The process's status words (int32[WORDS], pinned host memory the device writes), registered with the library on
     first use."""
-    global _words
+    global _words, _view
     if _words is None:
         w = torch.zeros(WORDS, dtype=torch.int32).pin_memory()
         L.check(L.load().avi_set_status_words(w.data_ptr()), "avi_set_status_words")
-        _words = w
+        _words, _view = w, w.numpy()
     return _words
 
 
 def read():
     """(overflow, tiny, pair_timeout) as seen by the host NOW: no synchronisation, so a pass still in flight may not
     have reported yet."""
-    w = words()
-    return bool(w[F16_OVERFLOW]), bool(w[F16_TINY]), bool(w[PAIR_TIMEOUT])
+    words()
+    return bool(_view[F16_OVERFLOW]), bool(_view[F16_TINY]), bool(_view[PAIR_TIMEOUT])
 
 
 def clear():
-    words().zero_()
+    words()
+    _view[:] = 0
+
+
+def clear_word(k):
+    words()
+    _view[k] = 0
 
 
 def raise_if_set(clear_after=True):
