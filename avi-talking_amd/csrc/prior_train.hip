@@ -227,7 +227,9 @@ template <class DOUT, class DQ>
 __device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* __restrict__ qkvb, const float* __restrict__ null_kv,
                                                 const float* relb, const float* __restrict__ rot_cos,
                                                 const float* __restrict__ rot_sin, DOUT dout, DQ dq, float* __restrict__ dnull_kv,
-                                                float* __restrict__ drel, AttnB& c) {
+                                                float* __restrict__ drel, float* __restrict__ part, AttnB& c) {
+    // part != nullptr: this (layer, sample)'s 96 relative-bias and 128 null-kv gradient contributions are STORED there and
+    // summed in sample order by prior_attn_grad_kernel (deterministic); nullptr: float atomics into drel / dnull_kv
     const int lane = t & 63, wave = t >> 6;
     if (live) {
         for (int vix = wave; vix < 28; vix += 4) {
@@ -288,7 +290,10 @@ __device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* _
     }
     __syncthreads();
     if (live) {
-        if (t < 96) atomicAdd(&drel[t], (&c.ds[0][0][0])[t]);
+        if (t < 96) {
+            if (part) part[t] = (&c.ds[0][0][0])[t];
+            else atomicAdd(&drel[t], (&c.ds[0][0][0])[t]);
+        }
         const int j = wave, d = lane;
         float a = 0.f, kk = 0.f;
         for (int h = 0; h < 8; ++h)
@@ -297,8 +302,12 @@ __device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* _
                 a = fmaf(c.p[h][i][j], dout(i, h * 64 + d), a);
                 kk = fmaf(c.ds[h][i][j], c.qn[h][i][d], kk);
             }
-        if (j == 0) atomicAdd(&dnull_kv[64 + d], a);
-        else dq(j - 1, 576 + d, a);
+        if (j == 0) {
+            if (part) part[96 + 64 + d] = a;
+            else atomicAdd(&dnull_kv[64 + d], a);
+        } else {
+            dq(j - 1, 576 + d, a);
+        }
         c.dkn[j][d] = kk;
     }
     __syncthreads();
@@ -330,6 +339,8 @@ __device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* _
                 dq(i, h * 64 + lane, dx * 16.0f);
             } else if (vix < 27) {
                 dq(vix - 24, 512 + lane, dx);
+            } else if (part) {
+                part[96 + lane] = dx;
             } else {
                 atomicAdd(&dnull_kv[lane], dx);
             }
@@ -337,6 +348,8 @@ __device__ __forceinline__ void attn_bwd_sample(int t, bool live, const float* _
     }
     __syncthreads();
 }
+
+constexpr int ATTN_PART = 96 + 128;     // floats per (layer, sample) of AviPriorTrainBwd.attn_part
 
 __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdArgs args_by_value, int B, int S) {
     const TrainBwdArgs& a = bargs();
@@ -438,8 +451,9 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
                 put_x<0>(s, rb + i, c, v);
                 dyq[i * NQKV + c] = v;
             };
+            float* part = d.attn_part ? d.attn_part + ((long long)l * B + b0 + (live ? sm : 0)) * ATTN_PART : nullptr;
             attn_bwd_sample(tid & 255, live, qkvb, w.layer[l].null_kv, s.relb, w.rot_cos, w.rot_sin, dout, dq,
-                            d.dnull_kv[l], d.drel, s.at[half]);
+                            d.dnull_kv[l], d.drel, part, s.at[half]);
         }
         Lin<NQKV, DIM>::template run<false, SmemB, true>(P.qkv_hi, P.qkv_lo, ring, s);                    // dn1 [R][128]
         __syncthreads();
@@ -470,6 +484,23 @@ __global__ __launch_bounds__(NT, 2) void prior_train_bwd_kernel(const TrainBwdAr
 // the null-kv gradients are accumulated with atomics: zeroed by this launch first, so that the caller need not clear the
 // gradient buffer (grid depth, 128 threads)
 __global__ __launch_bounds__(128) void prior_zero_null_kv_kernel(AviPriorTrainBwd d) { d.dnull_kv[blockIdx.x][threadIdx.x] = 0.f; }
+
+// null-kv gradient of layer l = sum over the samples, in sample order, of the stored contributions (block l < depth, 128
+// threads); block `depth`: the relative-bias gradient = sum over layers, then samples (96 threads; the bias table is shared
+// by the layers).  Plain stores: run-to-run identical, unlike the atomics they replace.
+__global__ __launch_bounds__(128) void prior_attn_grad_kernel(AviPriorTrainBwd d, int B, int depth) {
+    const int l = blockIdx.x, t = threadIdx.x;
+    if (l < depth) {
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += d.attn_part[((long long)l * B + b) * ATTN_PART + 96 + t];
+        d.dnull_kv[l][t] = v;
+    } else if (t < 96) {
+        float v = 0.f;
+        for (int ll = 0; ll < depth; ++ll)
+            for (int b = 0; b < B; ++b) v += d.attn_part[((long long)ll * B + b) * ATTN_PART + t];
+        d.drel[t] = v;
+    }
+}
 
 // gain gradient = sum of the workgroups' partials, in workgroup order: grid (depth * 3), 128 threads
 __global__ __launch_bounds__(128) void prior_gain_grad_kernel(const float* __restrict__ part, int groups, int depth,
@@ -575,8 +606,9 @@ extern "C" int avi_prior_train_backward(const AviPriorWeights* w, const AviPrior
     args.d = *d;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (B + samples_per_group - 1) / samples_per_group;
-    hipLaunchKernelGGL(prior_zero_null_kv_kernel, dim3(w->depth), dim3(128), 0, s, *d);
+    if (!d->attn_part) hipLaunchKernelGGL(prior_zero_null_kv_kernel, dim3(w->depth), dim3(128), 0, s, *d);
     hipLaunchKernelGGL(prior_train_bwd_kernel, dim3(groups), dim3(NT), sizeof(SmemB), s, args, B, samples_per_group);
     hipLaunchKernelGGL(prior_gain_grad_kernel, dim3(w->depth * 3), dim3(128), 0, s, d->dgamma_part, groups, w->depth, *gains);
+    if (d->attn_part) hipLaunchKernelGGL(prior_attn_grad_kernel, dim3(w->depth + 1), dim3(128), 0, s, *d, B, w->depth);
     return avi_launch_status();
 }

@@ -92,13 +92,37 @@ def grad_spans(depth=6, n_blocks=4):
     return spans
 
 
-class GradSync:
-    """Data-parallel gradient sum over the flat gradient buffer: one all-reduce per span, launched from inside backward
-    the moment a span is final (``ready``), the no-decay tail and the waits at the end (``finish``).  Device-agnostic:
-    "nccl" (= RCCL) on the GPU, "gloo" in the CPU tests.  Replaces the reference's dead ``distributed`` branches
-    (train_diffusion_prior.py:338,442,450)."""
+SHARD_ALIGN = 8          # elements: a rank's slice of a bucket starts on a 32-byte boundary (16-byte aligned 16-bit planes)
 
-    def __init__(self, layout, depth=6, n_blocks=4, process_group=None):
+
+def shard_of(a, b, world, rank):
+    """How bucket [a, b) of the flat buffers is divided among ``world`` ranks for the SHARDED optimizer:
+    -> (lo, hi, main_end): rank r owns [a + r c, a + (r + 1) c) with c = the largest multiple of SHARD_ALIGN such that
+    world * c <= b - a; [main_end, b) - fewer than world * SHARD_ALIGN elements - is the bucket's tail, which every rank
+    updates redundantly from an all-reduced gradient."""
+    c = (b - a) // (world * SHARD_ALIGN) * SHARD_ALIGN
+    return a + rank * c, a + (rank + 1) * c, a + world * c
+
+
+class GradSync:
+    """Data-parallel gradient exchange over the flat gradient buffer, bucket by bucket, launched from inside backward the
+    moment a bucket is final (``ready``), the no-decay tail and the waits at the end (``finish``).  Device-agnostic: "nccl"
+    (= RCCL) on the GPU, "gloo" in the CPU tests.  Replaces the reference's dead ``distributed`` branches
+    (train_diffusion_prior.py:338,442,450).
+
+    Two schedules:
+      * ``shard=False``: one all-reduce per bucket; every rank then runs the whole AdamW (28 B of HBM traffic per parameter
+        on every rank, on identical data).
+      * ``shard=True`` (default, AVI_DP_SHARD=0 switches it off): the optimizer state is SHARDED over the ranks, ZeRO-1
+        style.  Per bucket: reduce-scatter of the gradient (each rank receives the sum of ITS 1/world slice, in place),
+        fused AdamW on that slice only (``on_span``), all-gather of the updated fp32 parameters (in place; ``on_gathered``
+        then rebuilds the bf16 planes of the slices this rank did not own).  Same bytes on the wire as the all-reduce
+        (reduce-scatter + all-gather IS how a bandwidth-optimal all-reduce moves them), 1/world of the optimizer's HBM
+        traffic and time per rank, and the all-gather of bucket i runs beside the AdamW of bucket i + 1.  Fewer than
+        world * SHARD_ALIGN elements per bucket (its tail) are all-reduced and updated by every rank.
+        gloo has no reduce-scatter: there the slice's sum is taken from an all-reduce of the bucket (same values)."""
+
+    def __init__(self, layout, depth=6, n_blocks=4, process_group=None, shard=None):
         import os
         self.layout, self.pg = layout, process_group
         self.expected = [layout.span(a, b) for a, b in grad_spans(depth, n_blocks)]
@@ -106,6 +130,42 @@ class GradSync:
         # AVI_DP_FORCE_COLLECTIVES=1: issue the collectives with a single rank too (rehearsal of the RCCL path on a
         # one-GPU box; an all-reduce over one rank leaves the buffer unchanged)
         self.force = os.environ.get("AVI_DP_FORCE_COLLECTIVES") == "1"
+        self.shard = (os.environ.get("AVI_DP_SHARD", "1") == "1") if shard is None else bool(shard)
+
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.pg) if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _exchange(self, G, a, b):
+        """Start the gradient exchange of bucket [a, b): -> list of work handles."""
+        import torch.distributed as dist
+        if not self.shard:
+            return bucketed_allreduce(G, [(a, b)], self.pg)
+        world = self.world()
+        lo, hi, main = shard_of(a, b, world, self.rank())
+        works = []
+        if main > a:
+            if dist.get_backend(self.pg) == "nccl":
+                # in place: the receive slice is send buffer + rank * count (NCCL / RCCL's in-place reduce-scatter)
+                works.append(dist.reduce_scatter_tensor(G[lo:hi], G[a:main], group=self.pg, async_op=True))
+            else:
+                works.append(dist.all_reduce(G[a:main], group=self.pg, async_op=True))
+        if b > main:
+            works.append(dist.all_reduce(G[main:b], group=self.pg, async_op=True))
+        return works
+
+    def _gather(self, P, a, b):
+        """Start the all-gather of the updated parameters of bucket [a, b) (every rank contributes its slice, in place)."""
+        import torch.distributed as dist
+        world = self.world()
+        lo, hi, main = shard_of(a, b, world, self.rank())
+        if main <= a:
+            return None
+        if dist.get_backend(self.pg) == "nccl":
+            return dist.all_gather_into_tensor(P[a:main], P[lo:hi], group=self.pg, async_op=True)
+        c = hi - lo                 # gloo: the list form, receive buffers = views of the parameter buffer
+        return dist.all_gather([P[a + r * c:a + (r + 1) * c] for r in range(world)], P[lo:hi].clone(), group=self.pg,
+                               async_op=True)
 
     def world(self):
         import torch.distributed as dist
@@ -126,30 +186,55 @@ class GradSync:
             raise RuntimeError(f"gradient span {first}..{last} announced out of order (position {i})")
         self.done.append(span)
         if launch and self._collectives():
-            self.works += bucketed_allreduce(G, [span], self.pg)
+            self.works.append(self._exchange(G, *span))
 
-    def finish(self, G, launch=True, on_span=None):
-        """Reduce the no-decay tail, wait for every bucket; returns the world size (AdamW scales by 1/world).
-        ``on_span(a, b)``: called for every span [a, b) of the flat buffer - the announced ones in announcement order, then
-        the tail - as soon as ITS all-reduce has been waited for on the current stream (the optimizer updates a bucket
-        while later buckets are still on the wire)."""
+    def finish(self, G, launch=True, on_span=None, P=None, on_gathered=None):
+        """Exchange the no-decay tail, wait for every bucket; returns the world size (AdamW scales by 1/world).
+        ``on_span(a, b)``: the optimizer's update of [a, b), called as soon as the gradient sum of [a, b) has been waited
+        for on the current stream (later buckets are still on the wire).  Unsharded: once per bucket - the announced ones
+        in announcement order, then the no-decay tail.  Sharded: per bucket for THIS RANK's slice and for the bucket's
+        few-element tail; then, with ``P`` (the flat parameter buffer), the all-gather of the bucket's updated parameters
+        is started at once, and when all buckets are through ``on_gathered(a, b)`` is called for every range whose
+        parameters arrived from another rank (the caller rebuilds what it derives from them)."""
         if len(self.done) != len(self.expected):
             raise RuntimeError(f"{len(self.expected) - len(self.done)} gradient spans were never announced")
         spans = self.done + [(self.layout.n_decay, self.layout.numel)]
         self.done = []
         world = self.world()
-        works = []
-        if launch and self._collectives():
-            L_ = self.layout
-            self.works += bucketed_allreduce(G, [(L_.n_decay, L_.numel)], self.pg)
-            works = self.works
-            if len(works) != len(spans):
-                raise RuntimeError("one collective per gradient span expected")
-        for i, span in enumerate(spans):
-            if works:
-                works[i].wait()
+        active = launch and self._collectives()
+        if active:
+            self.works.append(self._exchange(G, self.layout.n_decay, self.layout.numel))
+            if len(self.works) != len(spans):
+                raise RuntimeError("one gradient exchange per span expected")
+        sharded = active and self.shard
+        if sharded and on_span is not None and P is None:
+            raise ValueError("the sharded schedule updates one slice per rank: finish() needs P to gather the others")
+        rank = self.rank() if sharded else 0
+        gathers = []
+        for i, (a, b) in enumerate(spans):
+            if active:
+                for w in self.works[i]:
+                    w.wait()
+            if not sharded:
+                if on_span is not None:
+                    on_span(a, b)
+                continue
+            lo, hi, main = shard_of(a, b, world, rank)
             if on_span is not None:
-                on_span(*span)
+                if hi > lo:
+                    on_span(lo, hi)
+                if b > main:
+                    on_span(main, b)
+            if P is not None:
+                gathers.append((self._gather(P, a, b), a, lo, hi, main))
+        for work, a, lo, hi, main in gathers:
+            if work is not None:
+                work.wait()
+            if on_gathered is not None:
+                if lo > a:
+                    on_gathered(a, lo)
+                if main > hi:
+                    on_gathered(hi, main)
         self.works = []
         return world
 
@@ -370,6 +455,7 @@ class PriorTrainer:
         # AVI_TRAIN_FUSED_BWD=0: the dX chain of the denoiser's backward as ~90 launches (needs the fused forward's dumps)
         self.fused_backward = self.fused_forward and os.environ.get("AVI_TRAIN_FUSED_BWD", "1") == "1"
         self.bwd_samples_per_group = int(os.environ.get("AVI_TRAIN_BWD_SPG", "1"))
+        self.atomics = os.environ.get("AVI_TRAIN_ATOMICS", "0") == "1"
         self.refresh()
 
     # ------------------------------------------------------------------ data parallel (C1 of SURVEY.md section 2)
@@ -499,11 +585,15 @@ class PriorTrainer:
         if part is None or part.numel() < groups * self.depth * 3 * DIM:
             part = fw["dgamma_part"] = torch.empty(groups * self.depth * 3 * DIM, dtype=torch.float32, device=self.device)
             fw["dtok0"] = torch.empty((R, DIM), dtype=torch.float32, device=self.device)
+            # per (layer, sample) contributions to the null-kv and relative-bias gradients, summed in sample order by the
+            # launch's last kernel: no float atomics, the step is run-to-run deterministic (AVI_TRAIN_ATOMICS=1: the old way)
+            fw["attn_part"] = torch.empty(self.depth * B * 224, dtype=torch.float32, device=self.device)
         d = L.AviPriorTrainBwd()
         d.dtok_top = dtok.data_ptr()
         d.tok_in, d.qkv, d.o1, d.tokm, d.hff = (fw[k].data_ptr() for k in ("tok_in", "qkv", "o1", "tokm", "hff"))
         d.dy_w2, d.dy_w1, d.dy_out, d.dy_qkv = (ws[k]["dy"].data_ptr() for k in ("w2", "w1", "out", "qkv"))
         d.dtok0, d.dgamma_part, d.drel = fw["dtok0"].data_ptr(), part.data_ptr(), drel.data_ptr()
+        d.attn_part = None if self.atomics else fw["attn_part"].data_ptr()
         for l in range(self.depth):
             d.dnull_kv[l] = S.gptr(self.c + f"layers.{l}.0.null_kv")
         L.check(so.avi_prior_train_backward(C.byref(self._fweights), C.byref(self._tplanes_struct), C.byref(d),
@@ -791,10 +881,36 @@ class PriorTrainer:
 
     # ------------------------------------------------------------------ optimizer
     def allreduce_grads(self):
-        """DP: finish the gradient sum over ranks (RCCL all-reduce over xGMI).  The weight buckets were launched
-        from inside backward (``_grads_ready``); the small no-decay tail (biases, T5 table) goes last.  AdamW then
-        scales by 1/world."""
+        """Finish the gradient exchange of a step whose optimizer runs over the WHOLE buffer on this rank afterwards
+        (``optimizer_step``): the single-GPU path and the unsharded data-parallel schedule (AVI_DP_SHARD=0).  The weight
+        buckets were launched from inside backward (``_grads_ready``); the small no-decay tail (biases, T5 table) goes
+        last.  AdamW then scales by 1/world.  With ranks and the sharded schedule use ``dp_update`` instead: there a rank
+        holds the gradient sum of its own slices only."""
+        if self.sync.shard and self.sync._collectives():
+            raise RuntimeError("sharded data-parallel schedule: call dp_update(), not allreduce_grads() + optimizer_step()")
         return self.sync.finish(self.store.G)
+
+    def _repack_span(self, a, b):
+        """bf16 hi / lo planes of parameters [a, b) that another rank updated and the all-gather just delivered."""
+        S = self.store
+        L.check(L.load().avi_pack_weight_split(S.P.data_ptr() + 4 * a, 1, b - a, 1, S.HI.data_ptr() + 2 * a,
+                                               S.LO.data_ptr() + 2 * a, L.stream_ptr()), "avi_pack_weight_split")
+
+    def dp_update(self, lr=None, beta1=None, use_dyn=False, count=True):
+        """The data-parallel optimizer step after ``forward_backward``: bucket by bucket - as its gradient exchange completes
+        - fused AdamW on what this rank owns (GradSync: the whole bucket when unsharded, its 1/world slice + the bucket's
+        few-element tail when sharded), the all-gather of the updated parameters started at once, then the planes of the
+        slices other ranks own and the transposed planes.  Works without ranks too (every bucket owned here)."""
+        S = self.store
+        if count:
+            self.step_count += 1
+            if use_dyn:
+                self._set_dyn(self.lr if lr is None else lr, beta1)
+        world = self.sync.world()
+        self.sync.finish(S.G, on_span=lambda a, b: self._adamw_span(a, b, world, lr=lr, beta1=beta1, use_dyn=use_dyn),
+                         P=S.P, on_gathered=self._repack_span)
+        self.refresh()
+        return world
 
     def _set_dyn(self, lr, beta1=None):
         """Step-dependent AdamW scalars go through device memory so a captured graph can be replayed: the rate, the two
@@ -868,8 +984,7 @@ class PriorTrainer:
 
         for _ in range(warmup):                              # eager steps (with collectives when there are ranks)
             fb()
-            world = self.sync.finish(self.store.G)
-            self.optimizer_step(world=world, use_dyn=True)
+            self.dp_update(use_dyn=True)
         torch.cuda.synchronize(self.device)
         self._segs = []
         pool = torch.cuda.graph_pool_handle()
@@ -930,9 +1045,7 @@ class PriorTrainer:
             for graph, (first, last) in self._segs:
                 graph.replay()
                 self.sync.ready(G, first, last)                   # eager all-reduce of the bucket this segment completed
-            world = self.sync.world()
-            self.sync.finish(G, on_span=lambda a, b: self._adamw_span(a, b, world, use_dyn=True))
-            self.refresh()
+            self.dp_update(use_dyn=True, count=False)
         cur.wait_stream(s)
         return self._gout
 
@@ -942,8 +1055,10 @@ class PriorTrainer:
         rand = rand or self.draw(voxel.shape[0])
         out = self.forward_backward(voxel, clip_target, rand["times"], rand["noise"], temp, rand["brain_keep"],
                                     rand["image_keep"], rand["dropout_masks"])
-        world = self.allreduce_grads()
-        self.optimizer_step(lr, world, beta1=beta1)
+        if self.sync._collectives():          # ranks: per-bucket exchange -> update (sharded by default) -> gather
+            self.dp_update(lr, beta1)
+        else:
+            self.optimizer_step(lr, self.allreduce_grads(), beta1=beta1)
         return out
 
     # ------------------------------------------------------------------ hipGraph capture (single GPU)

@@ -96,7 +96,7 @@ class AviPriorTrainDump(C.Structure):
 
 class AviPriorTrainBwd(C.Structure):
     _fields_ = ([(n, _vp) for n in ("dtok_top", "tok_in", "qkv", "o1", "tokm", "hff", "dy_w2", "dy_w1", "dy_out", "dy_qkv",
-                                    "dtok0", "dgamma_part")] + [("dnull_kv", _vp * PRIOR_MAX_DEPTH), ("drel", _vp)])
+                                    "dtok0", "dgamma_part")] + [("dnull_kv", _vp * PRIOR_MAX_DEPTH), ("drel", _vp), ("attn_part", _vp)])
 
 
 class AviPriorGainGrads(C.Structure):

@@ -474,15 +474,108 @@ def measure_train(wp, dev, world, rank, local_rank, dist, args):
     lp, ln = float(out["loss_prior"].item()), float(out["loss_nce"].item())
     if not (lp == lp and ln == ln):
         raise ValueError("NaN loss")                       # train_diffusion_prior.py:135-137 check_loss
+    ms_step = dt / args.train_steps * 1e3
+    roof = None
+    if rank == 0:
+        try:
+            roof = train_roofline(PriorTrainer(wp, device=dev, lr=1e-4) if graph and dist is not None else tr, voxel, target,
+                                  temp, rand, ms_step)
+        except Exception as e:
+            roof = {"error": f"{type(e).__name__}: {e}"[:300]}
     return {"workload": "configs[2]: aligner+prior train step, batch 64 per GPU, fwd+bwd+fused AdamW"
                         + (", RCCL gradient all-reduce overlapped with backward" if world > 1 else ""),
-            "samples_per_s": round(world * B * args.train_steps / dt, 1), "ms_per_step": round(dt / args.train_steps * 1e3, 3),
+            "samples_per_s": round(world * B * args.train_steps / dt, 1), "ms_per_step": round(ms_step, 3),
             "steps": args.train_steps, "global_batch": world * B, "params_m": round(tr.store.numel / 1e6, 1),
             "allreduce_mb": round(tr.store.numel * 4 / 1e6, 1) if world > 1 else 0, "hipgraph": graph,
             "random_draws": "inside the captured step (Philox stream: times, noise, cond-drop and dropout masks)" if graph
                             else "recorded tensors",
             "gradient_buckets": [f"{a}..{b}" for a, b in __import__("avi_talking_amd.host.training", fromlist=["x"]).grad_spans()] if world > 1 else None,
-            "dtype": "bf16x3", "loss_prior": round(lp, 5), "loss_nce": round(ln, 5)}
+            "dtype": "bf16x3", "loss_prior": round(lp, 5), "loss_nce": round(ln, 5),
+            "optimizer_schedule": (("sharded over the ranks (reduce-scatter -> AdamW on the rank's 1/world slice -> all-gather)"
+                                    if tr.sync.shard else "all-reduce, every rank updates everything") if dist is not None
+                                   else "single GPU: one fused AdamW over the flat buffers"),
+            "roofline": roof}
+
+
+def train_roofline(tr, voxel, target, temp, rand, step_ms, reps=3):
+    """Roofline of the TRAINING half of the metric (~31 GFLOP of GEMMs + 28 B per parameter of optimizer
+    traffic per step at B = 64).  Event-timed on the launch stream, kernel by kernel, in eager passes of the same step:
+      * fused AdamW (`adamw_kernel`, HBM bound): algorithmic bytes = 28 B x parameters (fp32 p, m, v read + written, g read;
+        the kernel also writes the 4 B of bf16 planes per parameter, not counted) / its launch time (lr = 0 so the timed
+        launches leave the model alone);
+      * every GEMM launch of forward + backward (MFMA bound): 2 M N K batch / time, all launches together and the aligner's
+        4096 x 4096 layers (97 % of the FLOPs) on their own;
+      * the step against its HBM floor: optimizer traffic + the bf16 planes of every matrix read for the forward, the dX and
+        (as transposed planes rebuilt each step: read fp32, write planes) pass + the gradient written once."""
+    from avi_talking_amd import ops
+    S = tr.store
+    n = S.numel
+    evs = []
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tr._adamw_span(0, S.n_decay, 1, lr=0.0)
+        tr._adamw_span(S.n_decay, n, 1, lr=0.0)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    adam_ms = min(a.elapsed_time(b) for a, b in evs[1:])
+    adam_bytes = 28.0 * n
+    rec, marks = [], []
+    orig = ops.gemm_raw
+
+    def timed(**kw):
+        s = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        orig(**kw)
+        e1.record(s)
+        rec.append((e0, e1, kw["M"], kw["N"], kw["K"], kw.get("batch", 1)))
+    ops.gemm_raw = timed
+    tr.sync._collectives = lambda: False          # rank 0 alone runs this leg: bookkeeping only, no collective is issued
+    try:
+        for _ in range(reps + 1):
+            marks.append(len(rec))
+            tr.forward_backward(voxel, target, rand["times"], rand["noise"], temp, rand["brain_keep"], rand["image_keep"],
+                                rand["dropout_masks"])
+            tr.sync.finish(S.G, launch=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_raw = orig
+        del tr.sync._collectives
+    marks.append(len(rec))
+    passes = [rec[marks[i]:marks[i + 1]] for i in range(1, reps + 1)]
+    slots = len(passes[0])
+    if any(len(p) != slots for p in passes):
+        raise RuntimeError("the eager training passes issued different launch sequences")
+    tot_ms = tot_fl = big_ms = big_fl = 0.0
+    for k in range(slots):
+        _, _, M, N, K, bt = passes[0][k]
+        ms = min(p[k][0].elapsed_time(p[k][1]) for p in passes)
+        fl = 2.0 * M * N * K * bt
+        tot_ms, tot_fl = tot_ms + ms, tot_fl + fl
+        if max(M, N, K * bt) >= 4096 and min(max(M, N), max(N, K * bt), max(M, K * bt)) >= 4096:      # a 4096 x 4096 layer
+            big_ms, big_fl = big_ms + ms, big_fl + fl
+    floor_bytes = adam_bytes + n * (4.0 + 4.0 + 8.0) + n * 4.0
+    floor_ms = floor_bytes / 8e12 * 1e3
+    gemm = lambda name, fl, ms, cnt: {
+        "bound": "mfma", "kernel": name, "launches_per_step": cnt, "ms_per_step": round(ms, 3),
+        "algorithmic_gflop_per_step": round(fl / 1e9, 1), "achieved": round(fl / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "mfma_per_product": 3,
+        "mfma_issued_frac": round(3 * fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+        "note": "batch-64 GEMMs: M or K is 64, so a launch streams its whole weight matrix for 64 rows of work - bound by "
+                "the bytes of the bf16 planes, not by the matrix cores"}
+    return {"bound": "hbm", "kernel": "adamw_kernel (fused AdamW over the flat fp32 buffers, emits the bf16 hi/lo planes)",
+            "launches_per_step": 2, "avg_launch_us": round(adam_ms * 1e3 / 2, 1), "ms_per_step": round(adam_ms, 3),
+            "frac_of_step": round(adam_ms / step_ms, 3), "algorithmic_bytes_per_launch": int(adam_bytes / 2),
+            "achieved": round(adam_bytes / adam_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(adam_bytes / adam_ms / 1e6 / 8000.0, 4), "traffic": None,
+            "others": [gemm("all GEMM launches of forward + backward (gemm_kernel family, 3-term bf16)", tot_fl, tot_ms, slots),
+                       gemm("of these: the aligner's 4096 x 4096 layers (forward split-K, dX, dW)", big_fl, big_ms, None)],
+            "step_hbm_floor": {"bytes": int(floor_bytes), "ms_at_8_TB_s": round(floor_ms, 3),
+                               "step_ms": round(step_ms, 3), "floor_over_step": round(floor_ms / step_ms, 3),
+                               "what": "28 B/param optimizer + bf16 planes read for forward and dX (4 + 4 B/param) + transposed "
+                                       "planes rebuilt (4 B read + 4 B written per param) + gradient written once (4 B/param)"}}
 
 
 def gemm_family(kw):

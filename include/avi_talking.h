@@ -429,8 +429,12 @@ int avi_prior_train_forward(const AviPriorWeights* w, const AviPriorPlanes* p, c
  * gain gradients): from `dtok_top`, the gradient at the output of the last layer, to `dtok0`, the gradient of the token
  * rows.  `pT` holds the fragment-major planes of the TRANSPOSED matrices (avi_pack_fragment_planes, transpose = 1).  The
  * output gradient of every matrix is stored for the weight-gradient GEMMs (dy_*: [depth][3B][C], C = 128, 1024, 128, 640 for
- * linear2, linear1, to_out, to_q|to_kv); dnull_kv[l] ([2][64]) is zeroed and then accumulated with atomics, the
- * relative-bias gradient is ADDED (atomics) to drel ([8][3][4], cleared by the caller); dgamma_part: scratch >= ceil(B / samples_per_group) * depth * 3 * 128 floats. */
+ * linear2, linear1, to_out, to_q|to_kv); dgamma_part: scratch >= ceil(B / samples_per_group) * depth * 3 * 128 floats.
+ * attn_part: scratch of depth * B * 224 floats - every (layer, sample) STORES its 96 relative-bias and 128 null-kv gradient
+ * contributions there and the launch's last kernel sums them in sample order into dnull_kv[l] ([2][64]) and drel ([8][3][4]),
+ * plain stores: the step is run-to-run deterministic.  attn_part == NULL: dnull_kv[l] is zeroed and then accumulated with
+ * float atomics, the relative-bias gradient is ADDED (atomics) to drel (cleared by the caller): last-bit differences run
+ * to run. */
 typedef struct AviPriorTrainBwd {
     const float* dtok_top;
     const float *tok_in, *qkv, *o1, *tokm, *hff;      /* forward intermediates (AviPriorTrainDump) */
@@ -439,6 +443,7 @@ typedef struct AviPriorTrainBwd {
     float* dgamma_part;
     float* dnull_kv[AVI_PRIOR_MAX_DEPTH];
     float* drel;
+    float* attn_part;
 } AviPriorTrainBwd;
 typedef struct AviPriorGainGrads {
     float* g[AVI_PRIOR_MAX_DEPTH][3];                 /* gradients of norm.g, to_out.1.g, ff 0.g of every layer ([128], written) */

@@ -194,12 +194,12 @@ def _span_update_worker(rank, world, port, ret):
     lay = FlatLayout.of_state_dict(make_prior_weights(3), _layout())
     G = torch.full((lay.numel,), float(rank + 1))
     P = torch.zeros(lay.numel)
-    sync = GradSync(lay)
+    sync = GradSync(lay, shard=False)        # the unsharded schedule: every rank updates every bucket
     for a, b in grad_spans():
         sync.ready(G, a, b)
     seen = []
 
-    def update(a, b):                        # what PriorTrainer.replay_step_dp does per bucket: its own optimizer launch
+    def update(a, b):                        # what PriorTrainer.dp_update does per bucket: its own optimizer launch
         assert bool((G[a:b] == 3.0).all()), "a bucket was handed to the optimizer before its sum had arrived"
         P[a:b] += G[a:b] / world
         seen.append((a, b))
@@ -223,6 +223,82 @@ def test_per_bucket_optimizer_callback_world2():
         covered[a:b] += 1
     assert bool((covered == 1).all())
     assert bool((ret["P"] == 1.5).all())
+
+
+def test_shard_of_partitions_every_bucket():
+    """The sharded optimizer's slices: for every bucket of the shipped layout and several world sizes the ranks' slices
+    and the bucket's tail tile [a, b) exactly, slices are equal and 32-byte aligned, the tail is shorter than world * 8."""
+    from avi_talking_amd.host.training import FlatLayout, SHARD_ALIGN, _layout, grad_spans, shard_of
+    from avi_talking_amd.weights import make_prior_weights
+    lay = FlatLayout.of_state_dict(make_prior_weights(3), _layout())
+    buckets = [lay.span(a, b) for a, b in grad_spans()] + [(lay.n_decay, lay.numel)]
+    for world in (1, 2, 3, 8):
+        for a, b in buckets:
+            pos = a
+            for r in range(world):
+                lo, hi, main = shard_of(a, b, world, r)
+                assert lo == pos and (hi - lo) % SHARD_ALIGN == 0 and lo % SHARD_ALIGN == 0
+                assert hi - lo == (main - a) // world
+                pos = hi
+            assert pos == main and 0 <= b - main < world * SHARD_ALIGN
+    assert shard_of(0, 100, 1, 0) == (0, 96, 96)
+
+
+def _sharded_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from avi_talking_amd.host.training import FlatLayout, GradSync, _layout, grad_spans
+    from avi_talking_amd.weights import make_prior_weights
+    torch.set_num_threads(2)
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    G = _flat_grads(lay, w, rank)
+    P = torch.zeros(lay.numel)
+    for n in lay.names:
+        P[lay.offset[n]:lay.offset[n] + w[n].numel()] = w[n].reshape(-1).float()
+    sync = GradSync(lay)                     # default: sharded
+    assert sync.shard
+    for a, b in grad_spans():
+        sync.ready(G, a, b)
+    updated, arrived = torch.zeros(lay.numel), torch.zeros(lay.numel)
+
+    def update(a, b):                        # stand-in for the fused AdamW launch on [a, b): plain SGD on the mean gradient
+        P[a:b] -= 0.1 * G[a:b] / world
+        updated[a:b] += 1
+
+    def gathered(a, b):                      # ranges another rank updated: the trainer rebuilds their bf16 planes
+        arrived[a:b] += 1
+    assert sync.finish(G, on_span=update, P=P, on_gathered=gathered) == world
+    ret[f"P{rank}"], ret[f"updated{rank}"], ret[f"arrived{rank}"] = P.clone(), updated, arrived
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_world2_matches_single_process():
+    """ZeRO-1 schedule over gloo, world 2: reduce-scatter per bucket (gloo: the slice of an all-reduce), every rank updates
+    ITS slice of every bucket (+ the bucket's few-element tail), all-gather of the updated parameters.  Both ranks end with
+    the parameters a single process gets from the mean gradient - every element -; every element is updated by exactly
+    one rank (the tails by both), and what a rank did not update itself is reported as arrived."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    from avi_talking_amd.host.training import FlatLayout, _layout
+    from avi_talking_amd.weights import make_prior_weights
+    w = make_prior_weights(3)
+    lay = FlatLayout.of_state_dict(w, _layout())
+    P0 = torch.zeros(lay.numel)
+    for n in lay.names:
+        P0[lay.offset[n]:lay.offset[n] + w[n].numel()] = w[n].reshape(-1).float()
+    expect = P0 - 0.1 * (_flat_grads(lay, w, 0) + _flat_grads(lay, w, 1)) / 2
+    assert torch.equal(ret["P0"], ret["P1"]), "the ranks ended the step with different parameters"
+    scale = (expect - P0).abs().max().item()
+    err = (ret["P0"] - expect).abs().max().item()
+    print(f"sharded world-2 step vs single process: {err:.2e} (the step moved the parameters by {scale:.2e})")
+    assert scale > 0 and err < 2e-5 * scale
+    total = ret["updated0"] + ret["updated1"]
+    assert bool(((total == 1) | (total == 2)).all()) and int((total == 2).sum()) < 8 * 2 * 8     # tails only
+    for r in range(world):
+        assert bool(((ret[f"updated{r}"] + ret[f"arrived{r}"]) == 1).all())      # own or arrived, never both, never neither
 
 
 # ----------------------------------------------------------------------------- bench.py launcher
