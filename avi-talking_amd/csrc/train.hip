@@ -945,10 +945,13 @@ extern "C" int avi_adamw(float* p, const float* g, float* m, float* v, long long
                          float eps, float weight_decay, int step, float grad_scale, const float* dyn, uint16_t* hi,
                          uint16_t* lo, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || (n & 3) || step < 1 || ((hi == nullptr) != (lo == nullptr))) return AVI_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    // bias corrections in double from the fp32 betas the kernel multiplies with, rounded once: exactly what a caller puts into
+    // `dyn` (host/training.py _set_dyn), so a step driven by arguments and a replayed graph driven by `dyn` agree bit for bit
+    // (Adam's m / sqrt(v) amplifies a last-bit difference of a parameter into a visible fraction of lr a few steps later)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2, 256, 4096)), dim3(256), 0, S_(stream), p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), grad_scale, dyn, hi, lo);
+                       beta2, eps, weight_decay, bc1, rsqrt_bc2, grad_scale, dyn, hi, lo);
     return avi_launch_status();
 }
 

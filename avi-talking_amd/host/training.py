@@ -918,6 +918,11 @@ class PriorTrainer:
         correction from the CURRENT beta1: 1 - beta1 ** step)."""
         b1, b2 = self.betas
         b1 = b1 if beta1 is None else float(beta1)
+        # the bias corrections exactly as avi_adamw forms them from its arguments (csrc/train.hip): in double, from the
+        # betas ROUNDED TO fp32 (what the kernel multiplies with) - a replayed graph and an argument-driven step then agree
+        # bit for bit
+        f32 = lambda x: torch.tensor(x, dtype=torch.float32).item()
+        b1, b2 = f32(b1), f32(b2)
         host = torch.tensor([lr, 1 - b1 ** self.step_count, 1 / math.sqrt(1 - b2 ** self.step_count), b1])
         self.dyn.copy_(host, non_blocking=True)
 

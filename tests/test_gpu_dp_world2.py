@@ -53,6 +53,12 @@ def _worker(rank, world, port, mode, ret):
         tr.capture_step_dp(voxel.to(dev), target.to(dev), 0.005, _to(rand, dev), warmup=1)   # = one eager DP step at lr 1e-3
         tr.replay_step_dp(lr=1e-3)
         tr.replay_step_dp(lr=2e-3)
+    elif mode == "eagerdyn":                # the eager step with the optimizer's scalars read from device memory, as the chain does
+        r = _to(rand, dev)
+        for lr in LRS:
+            tr.forward_backward(voxel.to(dev), target.to(dev), r["times"], r["noise"], 0.005, r["brain_keep"], r["image_keep"],
+                                r["dropout_masks"])
+            tr.dp_update(lr, use_dyn=True)
     else:
         for lr in LRS:
             tr.train_step(voxel.to(dev), target.to(dev), 0.005, rand=_to(rand, dev), lr=lr)
@@ -88,7 +94,7 @@ def _expected(gpu):
     return tr.store.P.cpu()
 
 
-@pytest.mark.parametrize("mode", ["segments/sharded", "eager/sharded", "segments/allreduce"])
+@pytest.mark.parametrize("mode", ["segments/sharded", "eager/sharded", "eagerdyn/sharded", "segments/allreduce"])
 def test_dp_step_world2_one_gpu(gpu, mode):
     """``sharded`` (the default): reduce-scatter per bucket, fused AdamW on the rank's own slice, all-gather of the updated
     parameters, planes of the other rank's slices rebuilt - each rank really updates only half of every bucket here;

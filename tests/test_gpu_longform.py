@@ -99,3 +99,44 @@ def test_fp16_coefficient_output_faceformer(gpu, monkeypatch, D, steps):
     assert h.dtype == torch.float16 and torch.equal(h, a.to(torch.float16))
     with pytest.raises(ValueError):
         ff.decode(hs, chunk=600, out_dtype=torch.bfloat16)
+
+
+def test_batch_whose_activations_exceed_2_31_elements(gpu):
+    """BASELINE configs[4] at a size where 32-bit element offsets break: 24 clips x 60 s make conv layer 0's output
+    24 x 191 999 x 512 = 2.36 G elements (4.7 GB per 16-bit plane).  Size-independent properties through the whole sampling
+    path on the default plan: a batch permutation permutes the outputs BIT-EXACTLY (every kernel's indexing is position
+    independent up to the last clip), and two rows of the big batch equal the same clips run as a batch of 2, which the CPU
+    oracle pins."""
+    from avi_talking_amd import weights as W
+    from avi_talking_amd.host.pipeline import SamplingPipeline
+    from oracle import emote as OE, prior as OP, wav2vec2 as OW
+    wa, wh, wp = W.make_wav2vec2_weights(0), W.make_emote_weights(1), W.make_prior_weights(3)
+    B, T = 24, 1500
+    g = torch.Generator().manual_seed(2424)
+    pcm = (torch.randn(B, T * 640, generator=g) * 3000).clamp(-32768, 32767).to(torch.int16)
+    voxel, noise = torch.randn(B, 768, generator=g), torch.randn(101, B, 1, 128, generator=g)
+    assert B * ((T * 640 - 10) // 5 + 1) * 512 > 2 ** 31
+    pipe = SamplingPipeline(wa, wh, wp, device=gpu, out_dtype=torch.float16)
+    d = [t.to(gpu) for t in (pcm, voxel, noise)]
+    out = pipe.run(*d)
+    exp, jaw = out["predicted_exp"].clone(), out["predicted_jaw"].clone()
+    assert exp.shape == (B, T, 50) and exp.dtype == torch.float16 and torch.isfinite(exp.float()).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(gpu)
+    outp = pipe.run(d[0][perm].contiguous(), d[1][perm].contiguous(), d[2][:, perm].contiguous())
+    assert torch.equal(outp["predicted_exp"], exp[perm]) and torch.equal(outp["predicted_jaw"], jaw[perm])
+    del outp
+    sub = [1, B - 1]                                     # the last clip sits beyond the 2^31-element mark in every big tensor
+    p32 = SamplingPipeline(wa, wh, wp, device=gpu)       # fp32 coefficients for the comparison with the oracle
+    small = p32.run(d[0][sub].contiguous(), d[1][sub].contiguous(), d[2][:, sub].contiguous())
+    e_rows = max((small["predicted_exp"] - exp[sub].float()).abs().max().item(),
+                 (small["predicted_jaw"] - jaw[sub].float()).abs().max().item())
+    feat = OW.forward(wa, OW.normalize_audio(pcm[sub], joint=False), frame_num=T)
+    te, _ = OP.brain_network(wp, voxel[sub])
+    ref = OE.forward(wh, feat, OP.p_sample_loop(wp, te.view(2, 1, 128), noise[:, sub]))
+    e_or = max((small["predicted_exp"].cpu() - ref["predicted_exp"]).abs().max().item(),
+               (small["predicted_jaw"].cpu() - ref["predicted_jaw"]).abs().max().item())
+    print(f"B = 24 x 60 s: rows of the big batch vs the batch of 2 {e_rows:.2e} (half-precision storage: 1e-3 x |coeff|), "
+          f"batch of 2 vs oracle {e_or:.2e}; peak memory {torch.cuda.max_memory_allocated(gpu) / 1e9:.1f} GB")
+    assert e_or < 3e-4                                   # the plan's gate
+    assert e_rows < 2e-3                                 # fp16 rounding of coefficients up to ~2 (2^-11 relative) + tile-shape order
+    pipe.synchronize()
