@@ -26,7 +26,13 @@ class FrozenCLIPEmbedder:
         self.eps = eps
         self.max_length = max_length
         self.tokenizer = tokenizer
+        # rows (prompts x tokens) up to which the fp32-operand GEMM with 64 x 64 tiles serves every projection; above it the
+        # plane-operand path, whose narrow projections (out_proj, fc2: N = 768) are cut along K while their 128-row tiles
+        # would not fill the chip (split_rows)
+        # MEASURED (round 4, one hipGraph per forward): 32 prompts = 2464 rows: fp32-operand path 2.69 ms (155 TFLOP/s), plane
+        # path 3.32 ms, plane path with K slices 2.73 ms; 64 prompts: plane path 4.30 ms, with K slices 4.19 ms (200 TFLOP/s)
         self.small_rows = int(os.environ.get("AVI_CLIP_SMALL_ROWS", "3072"))
+        self.split_rows = int(os.environ.get("AVI_CLIP_SPLIT_ROWS", "6144"))
         # checkpoints of CLIPTextModel carry a "text_model." prefix; newer transformers state_dicts drop it
         w = {(k[len("text_model."):] if k.startswith("text_model.") else k):
              v.detach().to(self.device, torch.float32).contiguous()
@@ -92,14 +98,19 @@ class FrozenCLIPEmbedder:
                 f = ops.linear(x, ly.fc1, act=ops.ACT_QUICK_GELU)
                 h = ops.linear(f, ly.fc2, residual=h)
             return ops.layernorm(h, *self.final, eps=self.eps)
+        # A batch of 32 prompts is 2464 rows: 20 row tiles of 128.  q|k|v (N = 2304) and fc1 (N = 3072) make 240 tiles of
+        # 128 x 192 / 128 x 256 - one round of the chip - but out_proj and fc2 (N = 768) only 60-80; cut along K (2 and 4
+        # slices) they launch 160 and 240 workgroups, the partial sums folded with bias and residual by one small launch
+        split = B * T <= self.split_rows and C % (2 * 96) == 0
         for ly in self.layers:
             _, xp = ops.layernorm_planes(h, *ly.ln1, eps=self.eps, want_f32=False)
             qkv = ops.linear_planes(xp, ly.qkv)                                          # (B, T, 3C) fp32
             att = ops.attention_d64_planes(qkv, H, 64 ** -0.5, bias_mode=2, slopes=self.zero_slopes, period=1)
-            h = ops.linear_planes(att, ly.out, residual=h)
+            h = ops.linear_planes_splitk(att, ly.out, 2, residual=h) if split else ops.linear_planes(att, ly.out, residual=h)
             _, xp = ops.layernorm_planes(h, *ly.ln2, eps=self.eps, want_f32=False)
             f = ops.linear_planes(xp, ly.fc1, act=ops.ACT_QUICK_GELU, out_planes=True)
-            h = ops.linear_planes(f, ly.fc2, residual=h)
+            h = (ops.linear_planes_splitk(f, ly.fc2, 4, residual=h) if split and ly.fc2.K % (4 * 96) == 0
+                 else ops.linear_planes(f, ly.fc2, residual=h))
         return ops.layernorm(h, *self.final, eps=self.eps)
 
     def forward(self, text):

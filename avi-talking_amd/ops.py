@@ -489,6 +489,32 @@ def linear_planes(xp, pw, act=ACT_NONE, residual=None, prec=PREC_BF16X3, out=Non
     return out
 
 
+def linear_planes_splitk(xp, pw, nsplit, residual=None, prec=PREC_BF16X3, cus=0):
+    """out = x @ W^T + b + residual for plane input with K cut into ``nsplit`` slices: one batched launch of the plane-operand
+    GEMM over the slices (partial sums in fp32) + ``avi_splitk_epilogue`` (adds them in slice order, bias, residual).  For
+    a few hundred rows and a narrow N the data-parallel launch has too few 128-row tiles for 256 CUs (2464 x 768: 80 tiles);
+    slices of K multiply the tile count.  K / nsplit must itself tile for the ping-pong kernels (a multiple of 96)."""
+    K = xp.shape[-1]
+    if K != pw.K or pw.N <= 64 or nsplit < 2 or K % nsplit or (K // nsplit) % 96:
+        raise ValueError("linear_planes_splitk: K / nsplit must be a multiple of 96 (and N > 64)")
+    if (prec & 0xff) != PREC_BF16X3 or xp.fmt != PLANES_BF16:
+        raise ValueError("linear_planes_splitk: 3-term bf16 planes only")
+    M = 1
+    for d in xp.shape[:-1]:
+        M *= d
+    N, ks = pw.N, K // nsplit
+    dev = xp.hi.device
+    if residual is not None and _f32c(residual, "residual").numel() != M * N:
+        raise ValueError("linear_planes_splitk: bad residual shape")
+    parts = torch.empty((nsplit, M, N), dtype=torch.float32, device=dev)
+    gemm_raw(Ahi=xp.hi.data_ptr(), Alo=xp.lo.data_ptr(), lda=K, Whi=pw.hi.data_ptr(), Wlo=pw.lo.data_ptr(), C_=parts.data_ptr(),
+             ldc=N, M=M, N=N, K=ks, prec=prec, batch=nsplit, sA=(ks, 0), sW=(ks, 0), sC=(M * N, 0), ldw=K, cus=cus)
+    out = torch.empty(tuple(xp.shape[:-1]) + (N,), dtype=torch.float32, device=dev)
+    L.check(L.load().avi_splitk_epilogue(parts.data_ptr(), nsplit, M * N, M, N, L.ptr(pw.bias), None, None, 1e-5, 0, ACT_NONE,
+                                         L.ptr(residual), out.data_ptr(), L.stream_ptr()), "avi_splitk_epilogue")
+    return out
+
+
 def layernorm_planes(x, gamma, beta, eps=1e-5, out=None, want_f32=True, fmt=PLANES_BF16):
     """LayerNorm emitting the result as fp32 (optional) and as split planes for the next GEMM."""
     x = _f32c(x, "x")

@@ -699,8 +699,11 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
             return out
         setattr(ops, name, timed)
 
+    shape_of = {}
+
     def gemm_work(a, kw, out):
         p = kw.get("prec", 3) & 0xff
+        shape_of[len(rec)] = (kw["M"], kw["N"], kw["K"], kw.get("batch", 1))      # this launch's slot in `rec`
         return (f"{gemm_family(kw)} [{PREC_NAME[p]}]", "mfma", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("batch", 1),
                 NS_OF_PREC[p])
 
@@ -779,7 +782,7 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
     n_slots = len(per_pass[0])
     if any(len(p_) != n_slots for p_ in per_pass):
         raise RuntimeError("the eager passes issued different launch sequences")
-    fam = {}
+    fam, shapes = {}, {}
     for slot in range(n_slots):
         _, _, name, bound, units, ns = per_pass[0][slot]
         ms = min(p_[slot][0].elapsed_time(p_[slot][1]) for p_ in per_pass)
@@ -787,6 +790,11 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
         f[0] += ms
         f[1] += units
         f[2] += 1
+        shp = shape_of.get(marks[1] + slot)
+        if shp is not None:           # per problem shape of a GEMM family: the rows a kernel trace's per-shape summary holds
+            s_ = shapes.setdefault(name, {}).setdefault(shp, [0.0, 0])
+            s_[0] += ms
+            s_[1] += 1
 
     def load_kernels(stem):
         path = latest_profile(stem)
@@ -838,7 +846,10 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
                       "algorithmic_gflop_per_step": round(units / 1e9, 1),
                       # matrix-pipe busy cycles / (kernel cycles x 1024 SIMDs), rocprofv3 PMC pass (kernels serialised by
                       # the profiler, i.e. the kernel alone on the chip)
-                      "mfma_busy_pmc": pmc_lookup(busy, name, "mfma_busy_frac")})
+                      "mfma_busy_pmc": pmc_lookup(busy, name, "mfma_busy_frac"),
+                      "by_shape": [{"M": m_, "N": n_, "K": k_, "batch": b_, "launches_per_step": c_, "avg_launch_us": round(t_ / c_ * 1e3, 1),
+                                    "achieved_tflops": round(2.0 * m_ * n_ * k_ * b_ * c_ / t_ / 1e9, 1)}
+                                   for (m_, n_, k_, b_), (t_, c_) in sorted(shapes.get(name, {}).items(), key=lambda kv: -kv[1][0])]})
         else:
             gbps = units / (ms * 1e-3) / 1e9
             e.update({"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),

@@ -21,19 +21,26 @@ def main():
     per = defaultdict(lambda: defaultdict(dict))                       # kernel -> dispatch -> counter -> value
     for f in files:
         for r in csv.DictReader(open(f)):
-            c = per[r["Kernel_Name"]][r["Dispatch_Id"]]
-            c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    out = {}
+            for key in (r["Kernel_Name"], (r["Kernel_Name"], int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))):
+                c = per[key][r["Dispatch_Id"]]
+                c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    out, shapes = {}, {}
     for k, disp in per.items():
         busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in disp.values())
         act = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in disp.values()) / 8.0
         if act <= 0 or busy <= 0:
             continue
-        name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        out[name] = {"launches": len(disp), "mfma_busy_cycles_per_launch": round(busy / len(disp)),
-                     "kernel_cycles_per_launch": round(act / len(disp)), "mfma_busy_frac": round(busy / (act * 1024.0), 4)}
+        kn = k[0] if isinstance(k, tuple) else k
+        name = kn.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        rec = {"launches": len(disp), "mfma_busy_cycles_per_launch": round(busy / len(disp)),
+               "kernel_cycles_per_launch": round(act / len(disp)), "mfma_busy_frac": round(busy / (act * 1024.0), 4)}
+        if isinstance(k, tuple):      # per problem shape: the launch's workgroup count tells the conv layers / M = 4000 / 8000 apart
+            shapes[f"{name} @ {k[1]} workgroups"] = rec
+        else:
+            out[name] = rec
     doc = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py; busy fraction = busy cycles / "
-                     "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)", "kernels": out}
+                     "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)", "kernels": out,
+           "by_shape": dict(sorted(shapes.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:60])}
     with open(out_path, "w") as fh:
         json.dump(doc, fh, indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:12]:

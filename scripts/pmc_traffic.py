@@ -20,9 +20,11 @@ def fold(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            a = acc[r["Kernel_Name"]]
-            a[0] += float(r["Counter_Value"])
-            a[1].add(r["Dispatch_Id"])
+            # per kernel, and per (kernel, problem shape): Grid_Size is the launch's thread count
+            for key in (r["Kernel_Name"], (r["Kernel_Name"], int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))):
+                a = acc[key]
+                a[0] += float(r["Counter_Value"])
+                a[1].add(r["Dispatch_Id"])
     return {k: (v[0], len(v[1])) for k, v in acc.items()}
 
 
@@ -33,8 +35,8 @@ def short(name):
 
 def main():
     fetch, write = fold(sys.argv[1], "FETCH_SIZE"), fold(sys.argv[2], "WRITE_SIZE")
-    out = {}
-    for k in sorted(set(fetch) | set(write)):
+    out, shapes = {}, {}
+    for k in sorted(set(fetch) | set(write), key=str):
         fk, fn = fetch.get(k, (0.0, 0))
         wk, wn = write.get(k, (0.0, 0))
         n = max(fn, wn)
@@ -42,11 +44,16 @@ def main():
             continue
         rd = fk * 1024.0 * 2.0 / max(fn, 1)          # KiB -> B, gfx950 half-count correction
         wr = wk * 1024.0 / max(wn, 1)
-        out[short(k)] = {"launches": n, "fetch_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                         "hbm_bytes_per_launch": round(rd + wr)}
+        rec = {"launches": n, "fetch_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+               "hbm_bytes_per_launch": round(rd + wr)}
+        if isinstance(k, tuple):
+            shapes[f"{short(k[0])} @ {k[1]} workgroups"] = rec
+        else:
+            out[short(k)] = rec
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py; FETCH_SIZE x 2 "
                      "(gfx950 counts 128-B read requests as 64 B), both counters in KiB",
-           "kernels": out}
+           "kernels": out,
+           "by_shape": dict(sorted(shapes.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:60])}
     with open(sys.argv[3], "w") as fh:
         json.dump(doc, fh, indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:

@@ -527,3 +527,27 @@ def test_plane_gemm_result_does_not_depend_on_the_tile_shape(gpu, monkeypatch, M
     for tile in ("5", "6"):
         for u, v in zip(got["4"], got[tile]):
             assert torch.equal(u, v), tile
+
+
+@pytest.mark.parametrize("M,N,K,nsplit", [(2464, 768, 768, 2), (2464, 768, 3072, 4), (300, 192, 576, 3)])
+def test_split_k_plane_linear(gpu, M, N, K, nsplit):
+    """ops.linear_planes_splitk (K slices as one batched plane-operand launch + the partial-sum epilogue) against the
+    data-parallel launch of the same product: equal up to the fp32 summation order of the slices, bias and residual included."""
+    from avi_talking_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(gpu)
+    w, b = (torch.randn(N, K, generator=g) / K ** 0.5).to(gpu), torch.randn(N, generator=g).to(gpu)
+    res = torch.randn(M, N, generator=g).to(gpu)
+    pw = ops.PackedWeight(w, b)
+    xp = ops.Planes((M, K), gpu)                                          # x = hi + lo in bf16, split on the host side of the test
+    hi = x.to(torch.bfloat16)
+    xp.hi.copy_(hi.view(torch.int16))
+    xp.lo.copy_((x - hi.float()).to(torch.bfloat16).view(torch.int16))
+    one = ops.linear_planes(xp, pw, residual=res)
+    cut = ops.linear_planes_splitk(xp, pw, nsplit, residual=res)
+    ref = xp.float().double() @ w.double().t() + b.double() + res.double()
+    e1, e2 = (one.double() - ref).abs().max().item(), (cut.double() - ref).abs().max().item()
+    print(f"M={M} N={N} K={K} / {nsplit}: data-parallel {e1:.2e}, split-K {e2:.2e} vs float64")
+    assert e2 < 2e-4 and (one - cut).abs().max().item() < 1e-4
+    with pytest.raises(ValueError):
+        ops.linear_planes_splitk(xp, pw, 5)
