@@ -35,3 +35,21 @@ extern "C" int avi_debug_raise_status(int k, void* stream) {
     hipLaunchKernelGGL(raise_status_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), avi_status_ptr(), k);
     return avi_launch_status();
 }
+
+// Diagnostics: where the workgroups of a launch run.  out[b] = XCC_ID << 16 | HW_ID[15:0] of workgroup b (HW_ID: wave, SIMD,
+// CU, shader array and shader engine ids within the XCD).  Used to probe CU masks of streams and the round-robin dealing of
+// workgroups over the XCDs (speed only: nothing in the library depends on placement for correctness).
+__global__ void where_kernel(unsigned* __restrict__ out, int spin) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);      // keep the slot busy so that later workgroups spread out
+    if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 0xf) << 16) | (hw & 0xffff);
+}
+extern "C" int avi_debug_where(unsigned* out, int blocks, int threads, int lds_bytes, int spin, void* stream) {
+    if (!out || blocks < 1 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || spin < 0) return AVI_EINVAL;
+    static AviLdsGrant lds_grant;
+    lds_grant.ensure(reinterpret_cast<const void*>(where_kernel), 160 * 1024);
+    hipLaunchKernelGGL(where_kernel, dim3(blocks), dim3(threads), lds_bytes, static_cast<hipStream_t>(stream), out, spin);
+    return avi_launch_status();
+}

@@ -186,6 +186,7 @@ SIGNATURES = {
     "avi_status_words": [],                                  # returns void* (RESTYPES below)
     "avi_debug_fault_inject": [_i],
     "avi_debug_raise_status": [_i, _vp],
+    "avi_debug_where": [_vp, _i, _i, _i, _i, _vp],
 }
 
 RESTYPES = {"avi_prior_pair_workspace_bytes": _ll, "avi_status_words": _vp}          # everything else returns an int status

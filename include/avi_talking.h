@@ -81,6 +81,10 @@ void* avi_status_words(void);
 #define AVI_FAULT_PAIR_PARTNER_ABSENT 1
 int avi_debug_fault_inject(int faults);
 int avi_debug_raise_status(int k, void* stream);
+/* avi_debug_where: out[b] = XCC_ID << 16 | HW_ID[15:0] of workgroup b of a launch of `blocks` x `threads` with `lds_bytes` of
+ * dynamic LDS, each holding its slot for `spin` x 64 sleep cycles: where a stream's workgroups land (CU masks, the dealing
+ * of workgroups over the XCDs).  Speed diagnostics only. */
+int avi_debug_where(unsigned* out, int blocks, int threads, int lds_bytes, int spin, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM with fused epilogue -- the dense contraction under every Linear / Conv1d
