@@ -252,6 +252,17 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
+
+    def marker():
+        """AVI_BENCH_MARKERS=1 (profiling runs): one `where_kernel` launch in front of and one behind the timed region, so
+        that scripts/trace_by_shape.py keeps exactly the timed passes of a kernel trace (outside the clock: each is followed
+        by a synchronisation)."""
+        if os.environ.get("AVI_BENCH_MARKERS") == "1":
+            mk = torch.zeros(1, dtype=torch.int32, device=dev)
+            L.check(L.load().avi_debug_where(mk.data_ptr(), 1, 64, 0, 0, L.stream_ptr()), "avi_debug_where")
+            torch.cuda.synchronize(dev)
+
+    marker()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -259,6 +270,7 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    marker()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
