@@ -811,12 +811,32 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
     def load_kernels(stem):
         path = latest_profile(stem)
         if not path:
-            return {}, None
+            return {}, {}, None
         with open(path) as fh:
-            return json.load(fh).get("kernels", {}), "profiles/" + os.path.basename(path)
+            doc = json.load(fh)
+        return doc.get("kernels", {}), doc.get("by_shape", {}), "profiles/" + os.path.basename(path)
 
-    traffic, tsrc = load_kernels("pmc_traffic.json")
-    busy, bsrc = load_kernels("pmc_mfma.json")
+    traffic, traffic_shapes, tsrc = load_kernels("pmc_traffic.json")
+    busy, busy_shapes, bsrc = load_kernels("pmc_mfma.json")
+
+    def shape_lookup(table, name, wgs, field):
+        """profiles' per-shape tables are keyed "<kernel> @ <workgroups> workgroups": the launch's tile count tells the conv
+        layers and the M = 4000 / 8000 projections of one kernel apart."""
+        base = name.split(" ")[0].split("<")[0]
+        f16 = "[f16x2]" in name
+        for k, v in table.items():
+            if not k.startswith(base) or not k.endswith(f"@ {wgs} workgroups"):
+                continue
+            if "NT=3" in name and ", 3," not in k or "NT=4" in name and ", 4," not in k:
+                continue
+            if base.startswith("gemm_pp") and (("true" in k.split("@")[0]) != f16):
+                continue
+            return v.get(field)
+        return None
+
+    def workgroups(name, m_, n_, b_):
+        bm, bn = (256, 256) if "(256x256)" in name else (128, 192) if "(128x192)" in name else (128, 256) if "(128x256)" in name else (0, 0)
+        return -(-m_ // bm) * -(-n_ // bn) * b_ if bm else None
 
     def pmc_lookup(table, name, field):
         """profiles' tables are keyed by the demangled kernel name: match on the kernel's base name and, for the
@@ -860,7 +880,11 @@ def measure_roofline(pipe, pcm, voxel, noise, step_ms, reps=3, pipelined=False):
                       # the profiler, i.e. the kernel alone on the chip)
                       "mfma_busy_pmc": pmc_lookup(busy, name, "mfma_busy_frac"),
                       "by_shape": [{"M": m_, "N": n_, "K": k_, "batch": b_, "launches_per_step": c_, "avg_launch_us": round(t_ / c_ * 1e3, 1),
-                                    "achieved_tflops": round(2.0 * m_ * n_ * k_ * b_ * c_ / t_ / 1e9, 1)}
+                                    "achieved_tflops": round(2.0 * m_ * n_ * k_ * b_ * c_ / t_ / 1e9, 1),
+                                    "frac": round(2.0 * m_ * n_ * k_ * b_ * c_ / t_ / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                    "workgroups": workgroups(name, m_, n_, b_),
+                                    "traffic": shape_lookup(traffic_shapes, name, workgroups(name, m_, n_, b_), "hbm_bytes_per_launch"),
+                                    "mfma_busy_pmc": shape_lookup(busy_shapes, name, workgroups(name, m_, n_, b_), "mfma_busy_frac")}
                                    for (m_, n_, k_, b_), (t_, c_) in sorted(shapes.get(name, {}).items(), key=lambda kv: -kv[1][0])]})
         else:
             gbps = units / (ms * 1e-3) / 1e9
