@@ -568,6 +568,14 @@ def train_roofline(tr, voxel, target, temp, rand, step_ms, reps=3):
         tot_ms, tot_fl = tot_ms + ms, tot_fl + fl
         if max(M, N, K * bt) >= 4096 and min(max(M, N), max(N, K * bt), max(M, K * bt)) >= 4096:      # a 4096 x 4096 layer
             big_ms, big_fl = big_ms + ms, big_fl + fl
+    adam_traffic = None
+    tp = latest_profile("pmc_train_traffic.json")      # rocprofv3 FETCH_SIZE / WRITE_SIZE passes over `bench.py --legs train`
+    if tp:
+        with open(tp) as fh:
+            shapes_ = json.load(fh).get("by_shape", {})
+        big = [v for k, v in shapes_.items() if k.startswith("adamw_kernel")]
+        if big:                                         # the decay region's launch (75 M of the 77.8 M parameters)
+            adam_traffic = max(v["hbm_bytes_per_launch"] for v in big)
     floor_bytes = adam_bytes + n * (4.0 + 4.0 + 8.0) + n * 4.0
     floor_ms = floor_bytes / 8e12 * 1e3
     gemm = lambda name, fl, ms, cnt: {
@@ -581,7 +589,9 @@ def train_roofline(tr, voxel, target, temp, rand, step_ms, reps=3):
             "launches_per_step": 2, "avg_launch_us": round(adam_ms * 1e3 / 2, 1), "ms_per_step": round(adam_ms, 3),
             "frac_of_step": round(adam_ms / step_ms, 3), "algorithmic_bytes_per_launch": int(adam_bytes / 2),
             "achieved": round(adam_bytes / adam_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(adam_bytes / adam_ms / 1e6 / 8000.0, 4), "traffic": None,
+            "frac": round(adam_bytes / adam_ms / 1e6 / 8000.0, 4), "traffic": adam_traffic,
+            "traffic_note": "HBM bytes of the decay region's launch from the PMC passes (profiles/), which also writes the 4 B of "
+                            "bf16 planes per parameter that the algorithmic 28 B do not count",
             "others": [gemm("all GEMM launches of forward + backward (gemm_kernel family, 3-term bf16)", tot_fl, tot_ms, slots),
                        gemm("of these: the aligner's 4096 x 4096 layers (forward split-K, dX, dW)", big_fl, big_ms, None)],
             "step_hbm_floor": {"bytes": int(floor_bytes), "ms_at_8_TB_s": round(floor_ms, 3),
