@@ -22,6 +22,8 @@ What is pinned:
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
   * fixture_chain.npz the fixture WAV (and two seeded clips) through the reference's wav2vec2 wrapper AND its EMOTE head +
                      FLINT decoder: audio -> coefficients on the reference's own modules (gen_fixture_chain).
+  * train_helpers.npz ``train_diffusion_prior.py``'s own ``soft_clip_loss`` / ``cosine_anneal`` / ``batchwise_cosine_similarity``
+                     / ``topk`` (the entry point imported as a module, everything it pulls in stubbed).
   * emote.npz        inferno ``LinearSequenceEncoder`` (SequenceEncoders.py:180-197), ``LinearEmotionCondition``
                      (FaceFormerDecoder.py:186-268), ``BertPriorDecoder.forward`` -> ``FeedForwardDecoder.forward/_style``,
                      ``_decode``, ``_post_prediction`` -> ``_apply_motion_prior`` (:598-682,1104-1224) with
@@ -507,6 +509,43 @@ def gen_fixture_chain():
     np.savez_compressed(os.path.join(HERE, "fixture_chain.npz"), **out)
 
 
+def gen_train_helpers():
+    """The loss / schedule helpers of the reference ENTRY POINT itself: ``train_diffusion_prior.py`` imported as a module
+    (its module-level imports of datasets, the EMOTE wrapper, pirender's meters, talkclip and dalle2 are MagicMock stubs -
+    none is on the executed path) and its own ``soft_clip_loss`` (:125-133), ``cosine_anneal`` (:122-123),
+    ``batchwise_cosine_similarity`` (:146-153) and ``topk`` (:139-145) run on seeded inputs of the training step's shapes
+    (B = 64 L2-normalised 128-d rows, the reference's temperatures 0.004 ... 0.0075)."""
+    import transformers  # noqa: F401
+    stub_modules()
+    for name in ["inferno_apps", "inferno_apps.TalkingHead", "inferno_apps.TalkingHead.evaluation",
+                 "inferno_apps.TalkingHead.evaluation.TalkingHeadWrapper",
+                 "inferno_apps.TalkingHead.evaluation.evaluation_functions", "inferno", "inferno.datasets",
+                 "inferno.datasets.FaceVideoDataModule", "dataset", "dataset.data_loader", "talkclip_text_generation",
+                 "talkclip_text_generation.text_gen", "emoca_utils", "models", "models.diffusion_prior"]:
+        m = MagicMock()
+        m.__all__ = []                      # `from ... import *` of a stub imports nothing
+        sys.modules[name] = m
+    ref = load_by_path("ref_train_entry", os.path.join(REF, "train_diffusion_prior.py"))
+    g = torch.Generator().manual_seed(2024)
+    out = {}
+    B = 64
+    preds = torch.nn.functional.normalize(torch.randn(B, 128, generator=g), dim=-1)
+    targs = torch.nn.functional.normalize(torch.randn(B, 128, generator=g) + 0.5 * preds, dim=-1)
+    out["preds"], out["targs"] = preds.numpy(), targs.numpy()
+    temps = ref.cosine_anneal(0.004, 0.0075, 40)
+    out["cosine_anneal_0.004_0.0075_40"] = temps.numpy()
+    out["cosine_anneal_1_0_7"] = ref.cosine_anneal(1.0, 0.0, 7).numpy()
+    for t in (0.004, 0.005, 0.0075, 0.125):
+        out[f"soft_clip_loss_T{t}"] = np.float64(ref.soft_clip_loss(preds, targs, temp=t))
+    sim = ref.batchwise_cosine_similarity(preds, targs)
+    out["batchwise_cosine_similarity"] = sim.numpy()
+    labels = torch.arange(B)
+    out["topk_1"] = np.float64(ref.topk(sim, labels, k=1))
+    out["topk_5"] = np.float64(ref.topk(sim, labels, k=5))
+    np.savez_compressed(os.path.join(HERE, "train_helpers.npz"), **out)
+    print("train_helpers.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
 def gen_clip_text():
     """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
     openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
@@ -534,8 +573,9 @@ def gen_clip_text():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain"):      # regenerate only one fixture
-        {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote, "fixture_chain": gen_fixture_chain}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain", "train_helpers"):      # one fixture
+        {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote, "fixture_chain": gen_fixture_chain,
+         "train_helpers": gen_train_helpers}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "faceformer_tf":
         gen_faceformer_teacher_forced(import_reference_models()[0])
@@ -546,6 +586,7 @@ if __name__ == "__main__":
     gen_emote()
     gen_fixture_chain()
     ff, dp = import_reference_models()
+    # (gen_train_helpers replaces `models*` in sys.modules by stubs: run it in its own process, `make_golden.py train_helpers`)
     gen_masks(ff)
     gen_brain(dp)
     gen_faceformer(ff)

@@ -314,3 +314,24 @@ def test_dp_segment_step_with_in_graph_draws(gpu, setup):
     l0 = float(tr.replay_step_dp()["loss_prior"])
     l1 = float(tr.replay_step_dp()["loss_prior"])
     assert rng.get_state() == (5, 12) and l0 == l0 and l1 == l1 and l0 != l1
+
+
+def test_soft_clip_loss_hip_matches_the_reference_entry_point(gpu):
+    """avi_soft_clip_loss against the reference's OWN soft_clip_loss (train_diffusion_prior.py:125-133 run on the imported
+    entry point, tests/golden/train_helpers.npz): no oracle in between.  B = 64 rows, the reference's temperatures."""
+    import os
+    import numpy as np
+    import avi_talking_amd.lib as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_helpers.npz"))
+    preds, targs = torch.from_numpy(g["preds"]).to(gpu), torch.from_numpy(g["targs"]).to(gpu)
+    B, D = preds.shape
+    for t in (0.004, 0.005, 0.0075, 0.125):
+        loss = torch.zeros(1, device=gpu)
+        dproj = torch.empty_like(preds)
+        scratch = torch.empty(2 * B * D + 2 * B + 3 * B * B, dtype=torch.float32, device=gpu)
+        L.check(L.load().avi_soft_clip_loss(preds.data_ptr(), targs.data_ptr(), B, D, float(t), 1.0, loss.data_ptr(),
+                                            dproj.data_ptr(), scratch.data_ptr(), L.stream_ptr()), "avi_soft_clip_loss")
+        ref = float(g[f"soft_clip_loss_T{t}"])
+        got = float(loss.item())
+        print(f"soft_clip_loss T={t}: HIP {got:.6f} reference {ref:.6f}")
+        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref))

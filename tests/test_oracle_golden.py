@@ -269,3 +269,41 @@ def test_rng_oracle_streams():
     assert set(np.unique(k)) == {0.0, 2.0} and abs((k > 0).mean() - 0.5) < 0.01
     t = OR.fill(5, 2, 1, OR.KIND_RANDINT_I32, 100000, 100.0)
     assert t.min() == 0 and t.max() == 99
+
+
+def test_training_loss_helpers_match_the_reference_entry_point():
+    """oracle.prior.soft_clip_loss / cosine_anneal and host.schedule.cosine_anneal against outputs of the reference's OWN
+    functions (train_diffusion_prior.py:122-133,139-153 run by make_golden.py::gen_train_helpers on the imported entry point)."""
+    from avi_talking_amd.host.schedule import cosine_anneal as host_anneal
+    from oracle import prior as OP
+    g = _load("train_helpers.npz")
+    preds, targs = torch.from_numpy(g["preds"]), torch.from_numpy(g["targs"])
+    for t in (0.004, 0.005, 0.0075, 0.125):
+        ref = float(g[f"soft_clip_loss_T{t}"])
+        got = float(OP.soft_clip_loss(preds, targs, temp=t))
+        assert abs(got - ref) <= 1e-6 * max(1.0, abs(ref)), (t, got, ref)
+    for key, args in (("cosine_anneal_0.004_0.0075_40", (0.004, 0.0075, 40)), ("cosine_anneal_1_0_7", (1.0, 0.0, 7))):
+        assert np.abs(OP.cosine_anneal(*args).numpy() - g[key]).max() < 1e-7
+        assert np.abs(np.array(host_anneal(*args), dtype=np.float64) - g[key]).max() < 1e-7
+    # the similarity matrix and top-k accuracies the reference logs from it (:488-496): restated here in two lines
+    sim = (preds / preds.norm(dim=1, keepdim=True)) @ (targs / targs.norm(dim=1, keepdim=True)).T
+    assert np.abs(sim.T.numpy() - g["batchwise_cosine_similarity"]).max() < 1e-6
+    top1 = float((torch.from_numpy(g["batchwise_cosine_similarity"]).argmax(1) == torch.arange(64)).float().mean())
+    assert abs(top1 - float(g["topk_1"])) < 1e-7
+
+
+@pytest.mark.parametrize("tag", ["fixture", "randn2"])
+def test_oracle_audio_to_coefficients_matches_the_reference_chain(tag):
+    """The oracle end to end - per-clip normalisation, wav2vec2 (frame_num = T), EMOTE head + FLINT decoder - on the reference's
+    fixture WAV and two seeded clips against the reference's own modules chained (make_golden.py::gen_fixture_chain)."""
+    g = _load("fixture_chain.npz")
+    pcm = torch.from_numpy(g[f"{tag}_pcm"].copy())
+    T = pcm.shape[1] // 640
+    wa, wh = W.make_wav2vec2_weights(0), W.make_emote_weights(1)
+    with torch.no_grad():
+        feat = OW.forward(wa, OW.normalize_audio(pcm, joint=False), frame_num=T)
+        out = OE.forward(wh, feat, torch.from_numpy(g[f"{tag}_style"]))
+    e_hid = np.abs(feat[:, ::5, ::16].numpy() - g[f"{tag}_hidden_slice"]).max()
+    e = max(np.abs(out["predicted_exp"].numpy() - g[f"{tag}_exp"]).max(), np.abs(out["predicted_jaw"].numpy() - g[f"{tag}_jaw"]).max())
+    print(f"{tag}: oracle vs the reference's wav2vec2 + EMOTE/FLINT chain: hidden {e_hid:.2e} coefficients {e:.2e}")
+    assert e_hid < 5e-5 and e < 2e-5
