@@ -108,8 +108,9 @@ def run_test(args):
     import numpy as np
     import torch
     from .. import weights as W
-    from .audio_io import process_audio, read_audio
+    from .audio_io import read_audio
     from .checkpoint import save_flame_pkl
+    from .sample import create_base_sample
     from .clip_text import FrozenCLIPEmbedder
     from .pipeline import SamplingPipeline
     dev = torch.device(args.device)
@@ -127,8 +128,10 @@ def run_test(args):
     for i, (text, audio_path) in enumerate(captions):
         audio_path = audio_path or args.test_audio_path
         wav, sr = read_audio(audio_path)
-        sample = process_audio(wav, sr, 25)
-        pcm = torch.from_numpy(sample["raw_audio"].reshape(1, -1).copy()).to(dev)
+        # the reference's own framing (trainer(): create_base_sample, train_diffusion_prior.py:695 -> evaluation_functions.py:
+        # 141-161), padding quirk included: T + 1 frames of 641 samples, the last frame and the last column zero
+        sample = create_base_sample(wav)
+        pcm = torch.from_numpy(sample["raw_audio"][None].copy()).to(dev)
         if clip is not None:                     # voxel = mean over the 77 token states (:710-711)
             voxel = clip(torch.from_numpy(tokens[i:i + 1]).to(dev)).mean(1)
         else:

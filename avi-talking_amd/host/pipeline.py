@@ -87,8 +87,15 @@ class SamplingPipeline:
     def _body(self, pcm, voxel, noise, clip_voxels=None, aligner_on_side=None):
         """Everything up to the join of the two branches: -> (audio features (B,T,768), sampled style (B,1,128)).
         ``clip_voxels``: the aligner's output when it was computed ahead (pipelined replay); None = compute it here."""
-        B, N = pcm.shape
-        T = N // 640
+        # pcm (B, N): 640 samples per frame (process_audio's framing); pcm (B, T, S): the caller's own frames, e.g. the
+        # (T + 1, 641) rows of the reference's create_base_sample (host/sample.py) - T frames come out either way
+        if pcm.dim() == 3:
+            B, T, S_ = pcm.shape
+            raw = pcm
+        else:
+            B, N = pcm.shape
+            T = N // 640
+            raw = pcm.view(B, T, 640)
         cur = torch.cuda.current_stream(self.device)
         # 1. Aligner MLP on the launch stream, before anything else (0.17 ms: split-K launches that stream the 300 MB
         #    of weights at HBM speed).  On the second stream its ten launches each queue behind resident GEMM
@@ -113,8 +120,7 @@ class SamplingPipeline:
         # the sampler's workgroups (one per samples_per_group samples) hold a CU each until the join: GEMM tile shapes of the
         # audio branch are chosen for the CUs that remain (avi_talking.h AviGemm.cus)
         free_cus = max(32, 256 - self.prior.cus_held(B))
-        sample = self.talking_head.forward_audio({"raw_audio": pcm.view(B, T, 640), "samplerate": [16000] * B},
-                                                 cus=free_cus)
+        sample = self.talking_head.forward_audio({"raw_audio": raw, "samplerate": [16000] * B}, cus=free_cus)
         # 3. join
         cur.wait_stream(self.side)
         return sample["audio_feature"], style
@@ -135,7 +141,7 @@ class SamplingPipeline:
         return buf
 
     def run(self, pcm, voxel, noise=None):
-        """pcm int16/fp32 (B, T*640) resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside
+        """pcm int16/fp32 (B, T*640) - or (B, T, samples per frame) - resident on the device, voxel (B,768), noise (T_d+1,B,1,128) or None (drawn inside
         the pass, ``rng_seed``) -> dict(predicted_exp (B,T,50), predicted_jaw (B,T,3), style_emb (B,1,128)).
         Asynchronous.  A device-side failure of an EARLIER pass (fp16 plane range, paired-sampler timeout: host/status.py)
         raises here, at the start of the next one, without any synchronisation; ``run_checked`` is the synchronous form

@@ -190,6 +190,17 @@ class TalkingHeadWrapper:
         self.head = EmoteHead(head_state_dict, device=device, prec=ops.fp32_operand_prec(prec))
         self.joint_norm = joint_norm        # AudioEncoders.py:170-178: HF processor sees ONE (B*L) array
 
+    # the three counts the reference's sample builders ask the wrapper for (TalkingHeadWrapper.py:113-121); the identity count
+    # follows from the style map's input width (expressions + intensities + identities + 300 shape coefficients)
+    def get_num_emotions(self):
+        return 8
+
+    def get_num_intensities(self):
+        return 3
+
+    def get_num_identities(self):
+        return self.head.cond_dim - 8 - 3 - 300
+
     def forward_audio(self, sample, cus=0, front_only=False):
         """Wav2Vec2Encoder._forward (AudioEncoders.py:165-200).  ``cus``: compute units free for the big GEMMs (0 = all).
         ``front_only``: stop in front of the 12 transformer layers and return their input (B, T, 768) instead of the sample

@@ -22,6 +22,8 @@ What is pinned:
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
   * fixture_chain.npz the fixture WAV (and two seeded clips) through the reference's wav2vec2 wrapper AND its EMOTE head +
                      FLINT decoder: audio -> coefficients on the reference's own modules (gen_fixture_chain).
+  * sample_dict.npz  the reference's own ``read_audio`` / ``process_audio`` / ``create_base_sample`` / ``create_condition`` /
+                     ``create_high_intensity_emotions`` on the fixture WAV (gen_sample_dict; own process, like train_helpers).
   * train_helpers.npz ``train_diffusion_prior.py``'s own ``soft_clip_loss`` / ``cosine_anneal`` / ``batchwise_cosine_similarity``
                      / ``topk`` (the entry point imported as a module, everything it pulls in stubbed).
   * emote.npz        inferno ``LinearSequenceEncoder`` (SequenceEncoders.py:180-197), ``LinearEmotionCondition``
@@ -493,8 +495,12 @@ def gen_fixture_chain():
     fix = torch.from_numpy(pcm[:T * 640].astype(np.float32))[None]
     g = torch.Generator().manual_seed(77)
     rnd = (torch.randn(2, 50 * 640, generator=g) * 3000).round().clamp(-32768, 32767)       # int16-valued, like raw_audio
-    for tag, x in (("fixture", fix), ("randn2", rnd)):
-        B, T = x.shape[0], x.shape[1] // 640
+    # the fixture as the reference's ENTRY POINT frames it: create_base_sample's padding line adds one zero frame and one
+    # zero sample column (raw_audio (125, 641), sample_dict.npz); the audio model sees the rows back to back, 125 frames
+    ref_frames = np.load(os.path.join(HERE, "sample_dict.npz"))["base_raw_audio"]
+    fix641 = torch.from_numpy(ref_frames.astype(np.float32).reshape(1, -1))
+    for tag, x, T in (("fixture", fix, None), ("randn2", rnd, None), ("fixture641", fix641, ref_frames.shape[0])):
+        B, T = x.shape[0], (x.shape[1] // 640 if T is None else T)
         xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-7)
         style = torch.randn(B, 1, 128, generator=g) * 0.5
         with torch.no_grad():
@@ -546,6 +552,64 @@ def gen_train_helpers():
     print("train_helpers.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 
 
+def gen_sample_dict():
+    """Row F / A0: the reference's OWN sample builders - ``read_audio`` / ``process_audio`` / ``create_base_sample`` /
+    ``create_condition`` / ``create_high_intensity_emotions`` of inferno_apps/TalkingHead/evaluation/evaluation_functions.py,
+    imported as they lie (renderers, mesh I/O, datasets stubbed; ``librosa.load`` - the decoder, absent here - is a functional
+    stand-in that returns the fixture WAV's channel 0 as floats at 16 kHz, everything after the decode is the reference's
+    code) and ``FpParser.recursive_collate`` semantics are not needed for the fixture.  The talking-head object the builders
+    query for three counts and two names is a stub with the released EMOTE config's values."""
+    import enum
+    for name in ["inferno_apps", "inferno_apps.TalkingHead", "inferno_apps.TalkingHead.evaluation",
+                 "inferno_apps.TalkingHead.evaluation.TalkingHeadWrapper", "inferno_apps.TalkingHead.utils",
+                 "inferno_apps.TalkingHead.utils.video", "inferno", "inferno.datasets", "inferno.datasets.FaceVideoDataModule",
+                 "inferno.utils", "inferno.utils.collate", "inferno.utils.PyRenderMeshSequenceRenderer",
+                 "inferno.datasets.AffectNetAutoDataModule", "trimesh", "soundfile", "psbody", "psbody.mesh",
+                 "inferno.utils.other", "librosa"]:
+        sys.modules[name] = MagicMock()
+
+    class AffectNetExpressions(enum.Enum):       # functional stand-in: only .Neutral.value and (value).name are used
+        Neutral, Happy, Sad, Surprise, Fear, Disgust, Anger, Contempt = range(8)
+    sys.modules["inferno.datasets.AffectNetAutoDataModule"].AffectNetExpressions = AffectNetExpressions
+    wav = os.path.join(REF, "experiments/wav_dir/0001/M012_front_neutral_level1_017.wav")
+    pcm0 = read_wav_ch0(wav)
+    sys.modules["librosa"].load = lambda path, sr=None: (pcm0.astype(np.float32) / 32768.0, 16000)
+    ev = load_by_path("ref_eval_functions", os.path.join(
+        REF, "third_party/inferno/inferno_apps/TalkingHead/evaluation/evaluation_functions.py"))
+    style = _munchify(dict(gt_expression_label=True, gt_expression_intensity=True, gt_expression_identity=True))
+    th = MagicMock()
+    th.cfg = _munchify(dict(data=dict(reconstruction_type=["EMICA-MEAD_flame2020"]),
+                            model=dict(sequence_decoder=dict(style_embedding=style))))
+    th.get_num_emotions.return_value, th.get_num_intensities.return_value, th.get_num_identities.return_value = 8, 3, 32
+    subjects = [f"M{i:03d}" for i in range(32)]
+    th.get_subject_labels.return_value = subjects
+    out = {}
+    wavdata, sr = ev.read_audio(wav)
+    out["read_audio"], out["read_audio_sr"] = wavdata, np.int64(sr)
+    fr = ev.process_audio(wavdata, sr, 25)
+    out["process_audio_raw"] = fr["raw_audio"]
+    base = ev.create_base_sample(th, wav)
+    out["base_raw_audio"] = base["raw_audio"]
+    rec = base["reconstruction"]["EMICA-MEAD_flame2020"]
+    out["base_rec_shapes"] = np.array([rec["gt_exp"].shape[0], rec["gt_exp"].shape[1], rec["gt_shape"].shape[0],
+                                       rec["gt_jaw"].shape[1], rec["gt_tex"].shape[0]])
+    for k in ("gt_expression_label_condition", "gt_expression_intensity_condition", "gt_expression_identity_condition"):
+        out["base_" + k] = base[k]
+    b2 = ev.create_base_sample(th, wav, smallest_unit=8, silent_frames_start=3, silent_frames_end=2)
+    out["base8_raw_audio_shape"] = np.array(b2["raw_audio"].shape)
+    out["base8_raw_audio_sum"] = np.float64(b2["raw_audio"].astype(np.float64).sum())
+    hs = ev.create_high_intensity_emotions(th, base, identity_list=[5, 30], emotion_index_list=[3, 6], intensity_list=[2, 0])
+    for i, h in enumerate(hs):
+        for k in ("gt_expression_label_condition", "gt_expression_intensity_condition", "gt_expression_identity_condition"):
+            out[f"hi{i}_{k}"] = h[k]
+        out[f"hi{i}_name"] = np.array(h["output_name"])
+    hq = ev.create_high_intensity_emotions(th, base, identity_list=[1], emotion_index_list=[4], intensity_list=[1],
+                                           silent_frames_start=4, silent_emotion_start=0)
+    out["hiq_gt_expression_label_condition"] = hq[0]["gt_expression_label_condition"]
+    np.savez_compressed(os.path.join(HERE, "sample_dict.npz"), **out)
+    print("sample_dict.npz:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
+
+
 def gen_clip_text():
     """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
     openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
@@ -573,9 +637,9 @@ def gen_clip_text():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain", "train_helpers"):      # one fixture
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain", "train_helpers", "sample_dict"):
         {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote, "fixture_chain": gen_fixture_chain,
-         "train_helpers": gen_train_helpers}[sys.argv[1]]()
+         "train_helpers": gen_train_helpers, "sample_dict": gen_sample_dict}[sys.argv[1]]()      # one fixture
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "faceformer_tf":
         gen_faceformer_teacher_forced(import_reference_models()[0])

@@ -59,7 +59,7 @@ def test_wav2vec2_hip_matches_reference_golden(gpu, tag, plan):
 
 
 @pytest.mark.parametrize("plan", PLANS)
-@pytest.mark.parametrize("tag", ["fixture", "randn2"])
+@pytest.mark.parametrize("tag", ["fixture", "randn2", "fixture641"])
 def test_audio_to_coefficients_hip_matches_reference_chain(gpu, tag, plan):
     """The reference's one real input (experiments/wav_dir/0001, channel 0) and two seeded clips from int16 PCM to FLAME
     coefficients: HIP (device-side normalisation -> wav2vec2 -> EMOTE head + FLINT) against the golden of the reference's own
@@ -69,11 +69,12 @@ def test_audio_to_coefficients_hip_matches_reference_chain(gpu, tag, plan):
     from avi_talking_amd.host.talking_head import TalkingHeadWrapper
     g = _load("fixture_chain.npz")
     pcm = torch.from_numpy(g[f"{tag}_pcm"].copy())
-    B, T = pcm.shape[0], pcm.shape[1] // 640
+    spf = 641 if tag.endswith("641") else 640      # "fixture641": the reference entry point's own framing (host/sample.py)
+    B, T = pcm.shape[0], pcm.shape[1] // spf
     if tag == "fixture":
         assert np.array_equal(pcm[0, :64].numpy(), _load("wav2vec2_fixture.npz")["pcm_head"])
     th = TalkingHeadWrapper(make_wav2vec2_weights(0), make_emote_weights(1), device=gpu, prec=plan, joint_norm=False)
-    out = th({"raw_audio": pcm.view(B, T, 640).to(gpu), "samplerate": [16000] * B},
+    out = th({"raw_audio": pcm.view(B, T, spf).to(gpu), "samplerate": [16000] * B},
              style_emb=torch.from_numpy(g[f"{tag}_style"]).to(gpu), is_external_style_emb=True)
     e_hid = np.abs(out["audio_feature"][:, ::5, ::16].cpu().numpy() - g[f"{tag}_hidden_slice"]).max()
     e_exp = np.abs(out["predicted_exp"].cpu().numpy() - g[f"{tag}_exp"]).max()

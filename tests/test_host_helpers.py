@@ -207,3 +207,42 @@ def test_default_plan_is_the_benchmarked_plan():
                faceformer.Faceformer.__init__):
         assert inspect.signature(fn).parameters["prec"].default is None
     assert cli.build_parser().parse_args([]).prec is None
+
+
+def test_sample_dict_builders_match_the_reference():
+    """host/sample.py against the reference's own ``process_audio`` / ``create_base_sample`` / ``create_condition`` /
+    ``create_high_intensity_emotions`` run on the fixture WAV (tests/golden/sample_dict.npz from make_golden.py::
+    gen_sample_dict): same arrays, same dtypes, same names - including what the reference's padding line really does (one extra
+    zero FRAME and one extra zero SAMPLE COLUMN at smallest_unit = 1: raw_audio (125, 641))."""
+    from avi_talking_amd.host import sample as S
+    from avi_talking_amd.host.audio_io import process_audio
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sample_dict.npz"))
+    wav = g["read_audio"]
+    assert wav.dtype == np.int16 and int(g["read_audio_sr"]) == 16000
+    fr = process_audio(wav, 16000, 25)
+    assert fr["raw_audio"].dtype == g["process_audio_raw"].dtype and np.array_equal(fr["raw_audio"], g["process_audio_raw"])
+    base = S.create_base_sample(wav)
+    assert base["raw_audio"].shape == (125, 641) and np.array_equal(base["raw_audio"], g["base_raw_audio"])
+    rec = base["reconstruction"]["EMICA-MEAD_flame2020"]
+    assert [rec["gt_exp"].shape[0], rec["gt_exp"].shape[1], rec["gt_shape"].shape[0], rec["gt_jaw"].shape[1],
+            rec["gt_tex"].shape[0]] == list(g["base_rec_shapes"])
+    for k in S.CONDITION_KEYS:
+        assert base[k].dtype == g["base_" + k].dtype and np.array_equal(base[k], g["base_" + k]), k
+    b8 = S.create_base_sample(wav, smallest_unit=8, silent_frames_start=3, silent_frames_end=2)
+    assert list(b8["raw_audio"].shape) == list(g["base8_raw_audio_shape"])
+    assert float(b8["raw_audio"].astype(np.float64).sum()) == float(g["base8_raw_audio_sum"])
+    subjects = [f"M{i:03d}" for i in range(32)]
+    hs = S.create_high_intensity_emotions(base, identity_list=[5, 30], emotion_index_list=[3, 6], intensity_list=[2, 0],
+                                          training_subjects=subjects)
+    for i, h in enumerate(hs):
+        for k in S.CONDITION_KEYS:
+            assert np.array_equal(h[k], g[f"hi{i}_{k}"]), (i, k)
+        assert h["output_name"] == str(g[f"hi{i}_name"])
+    hq = S.create_high_intensity_emotions(base, identity_list=[1], emotion_index_list=[4], intensity_list=[1],
+                                          silent_frames_start=4, silent_emotion_start=0)
+    assert np.array_equal(hq[0]["gt_expression_label_condition"], g["hiq_gt_expression_label_condition"])
+    col = S.recursive_collate(hs, device="cpu")
+    assert col["raw_audio"].shape == (2, 125, 641) and col["gt_expression_label_condition"].shape == (2, 125, 8)
+    assert col["reconstruction"]["EMICA-MEAD_flame2020"]["gt_exp"].shape == (2, 125, 50) and col["output_name"] == ["_M005_Surprise_2", "_M030_Anger_0"]
+    with pytest.raises(ValueError):
+        S.create_condition({}, emotions=[8])
