@@ -6,10 +6,16 @@
   ``named_parameters()`` order), ``lr_scheduler``, ``train_losses``, ``val_losses``, ``lrs``.
 * ``flame_*.pkl`` of ``evaluation_functions.py:624-638``: ``{"shape", "expression", "jaw_pose", "global_pose"}`` numpy arrays.
 
-Parameter ORDER inside a group matters for ``optimizer_state_dict`` (torch indexes parameters by position).  For
-``voxel2clip`` it is the registration order of the reference ``BrainNetwork`` (pinned by tests/golden/brain.npz key order);
-for ``net`` it is the order of ``avi_talking_amd.weights.make_prior_weights`` keys, which restates dalle2's registration
-order from memory (dalle2_pytorch is absent: unpinned, like the rest of that class - DESIGN.md section 2).
+Parameter ORDER inside a group matters for ``optimizer_state_dict`` (torch indexes parameters by position) and is the order
+of ``Module.named_parameters()``: a module's OWN parameters before its sub-modules', sub-modules in registration order
+(``torch_parameter_order``).  So in ``net`` the three direct parameters ``learned_query`` / ``null_brain_embeds`` /
+``null_image_embed`` (models/diffusion_prior.py:196,203-204) come before ``to_time_embeds`` and ``causal_transformer``, and
+inside every dalle2 ``Attention`` its direct ``null_kv`` before ``norm`` / ``to_q`` / ... (round 4: found by cross-loading
+with the reference's own ``save_ckpt`` / ``resume_ckpt``, tests/test_reference_live.py; the given key order used to be taken
+as is).  Sibling order: for ``voxel2clip`` the registration order of the reference ``BrainNetwork`` (pinned by
+tests/golden/brain.npz key order); for ``net`` the reference's constructors (:169-207, :119-152) and, inside the dalle2 blocks,
+the order of ``avi_talking_amd.weights.make_prior_weights`` keys, which restates dalle2's registration order from memory
+(dalle2_pytorch is absent: unpinned, like the rest of that class - DESIGN.md section 2).
 Loading uses ``torch.load(..., weights_only=True)``: checkpoints are data, never code."""
 import os
 import pickle
@@ -22,10 +28,32 @@ from .training import no_decay
 NET, V2C = "net.", "voxel2clip."
 
 
-def param_groups(names):
-    """The four groups of train_diffusion_prior.py:997-1003 as lists of parameter names, in the given order."""
-    g = [[], [], [], []]
+def torch_parameter_order(names):
+    """``names`` re-ordered the way ``torch.nn.Module.named_parameters()`` yields the parameters of the module tree the
+    dotted names imply: at every module its own parameters first (in the given order), then its sub-modules in the order
+    they first appear."""
+    tree = {"p": [], "c": {}}
     for n in names:
+        node = tree
+        parts = n.split(".")
+        for part in parts[:-1]:
+            node = node["c"].setdefault(part, {"p": [], "c": {}})
+        node["p"].append(n)
+    out = []
+
+    def walk(node):
+        out.extend(node["p"])
+        for child in node["c"].values():
+            walk(child)
+    walk(tree)
+    return out
+
+
+def param_groups(names):
+    """The four groups of train_diffusion_prior.py:997-1003 as lists of parameter names, each in ``named_parameters()``
+    order of its sub-model (``torch_parameter_order``)."""
+    g = [[], [], [], []]
+    for n in torch_parameter_order(names):
         if n.startswith(NET):
             g[1 if no_decay(n[len(NET):]) else 0].append(n)
         elif n.startswith(V2C):

@@ -22,6 +22,8 @@ What is pinned:
                      (DecaFLAME.py:236-244); inputs + a slice of the vertices.
   * fixture_chain.npz the fixture WAV (and two seeded clips) through the reference's wav2vec2 wrapper AND its EMOTE head +
                      FLINT decoder: audio -> coefficients on the reference's own modules (gen_fixture_chain).
+  * emote_audio.npz  EMOTE's own audio wrapper (AudioEncoders.py ``Wav2Vec2Encoder._forward`` + ``Wav2Vec2ModelResampled``) on
+                     int16 raw_audio: processor call with its joint statistics, desired_output_length, the ceil length rule.
   * sample_dict.npz  the reference's own ``read_audio`` / ``process_audio`` / ``create_base_sample`` / ``create_condition`` /
                      ``create_high_intensity_emotions`` on the fixture WAV (gen_sample_dict; own process, like train_helpers).
   * train_helpers.npz ``train_diffusion_prior.py``'s own ``soft_clip_loss`` / ``cosine_anneal`` / ``batchwise_cosine_similarity``
@@ -610,6 +612,42 @@ def gen_sample_dict():
     print("sample_dict.npz:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
 
 
+def gen_emote_audio():
+    """Rows A1-A4 through EMOTE's OWN audio wrapper: ``inferno/models/temporal/AudioEncoders.py`` imported as it lies
+    (``inferno.models.temporal.Bases.TemporalAudioEncoder`` = nn.Module, ``inferno.utils.other`` stubbed: neither is on the
+    executed path) - ``Wav2Vec2ModelResampled`` built by its constructor from the library-default config (= base-960h's
+    architecture) with our seeded weights, ``Wav2Vec2Encoder`` via ``__new__`` (its ``__init__`` fetches the pretrained model
+    and processor by name) with the installed ``Wav2Vec2FeatureExtractor`` as ``input_processor`` (the object the reference's
+    ``Wav2Vec2Processor`` forwards audio to) - and ``Wav2Vec2Encoder._forward(sample)`` run UNMODIFIED on int16 ``raw_audio``
+    (B, T, 640): the processor's joint-over-the-batch statistics (:170-178), ``desired_output_length = T``, the
+    ``ceil`` length rule of ``temporal_interpolation`` when no length is given."""
+    from transformers import Wav2Vec2Config, Wav2Vec2FeatureExtractor
+    bases = types.ModuleType("inferno.models.temporal.Bases")
+    bases.TemporalAudioEncoder = torch.nn.Module
+    for name, mod in (("inferno", MagicMock()), ("inferno.models", MagicMock()), ("inferno.models.temporal", MagicMock()),
+                      ("inferno.models.temporal.Bases", bases), ("inferno.utils", MagicMock()),
+                      ("inferno.utils.other", MagicMock())):
+        sys.modules[name] = mod
+    ae = load_by_path("ref_audio_encoders", os.path.join(REF, "third_party/inferno/inferno/models/temporal/AudioEncoders.py"))
+    model = ae.Wav2Vec2ModelResampled(Wav2Vec2Config(attn_implementation="eager")).eval()
+    print(model.load_state_dict(W.make_wav2vec2_weights(0), strict=True))
+    enc = ae.Wav2Vec2Encoder.__new__(ae.Wav2Vec2Encoder)
+    torch.nn.Module.__init__(enc)
+    enc.model, enc.resampling, enc.dropout, enc.trainable = model, True, None, False
+    enc.input_processor = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True,
+                                                   return_attention_mask=False)
+    g = torch.Generator().manual_seed(2025)
+    raw = (torch.randn(2, 30, 640, generator=g) * torch.tensor([800.0, 5000.0])[:, None, None]).to(torch.int16)
+    with torch.no_grad():
+        s = enc._forward({"raw_audio": raw.clone(), "samplerate": [16000, 16000]})
+        free = model(s["processed_audio"][:, :19000].contiguous()).last_hidden_state          # no length given: ceil rule
+    out = {"raw_audio": raw.numpy(), "processed_audio_slice": s["processed_audio"][:, ::97].numpy(),
+           "audio_feature_shape": np.array(s["audio_feature"].shape), "audio_feature_slice": s["audio_feature"][:, :, ::8].numpy(),
+           "free_len_input": np.int64(19000), "free_len_shape": np.array(free.shape), "free_len_slice": free[:, :, ::8].numpy()}
+    np.savez_compressed(os.path.join(HERE, "emote_audio.npz"), **out)
+    print("emote_audio.npz:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
+
+
 def gen_clip_text():
     """The class FrozenCLIPEmbedder wraps (models/diffusion_prior.py:40,52-53) with the text config of
     openai/clip-vit-large-patch14; from_pretrained needs the network, so the weights are the seeded random init."""
@@ -637,9 +675,9 @@ def gen_clip_text():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain", "train_helpers", "sample_dict"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("flame", "clip_text", "emote", "fixture_chain", "train_helpers", "sample_dict", "emote_audio"):
         {"flame": gen_flame, "clip_text": gen_clip_text, "emote": gen_emote, "fixture_chain": gen_fixture_chain,
-         "train_helpers": gen_train_helpers, "sample_dict": gen_sample_dict}[sys.argv[1]]()      # one fixture
+         "train_helpers": gen_train_helpers, "sample_dict": gen_sample_dict, "emote_audio": gen_emote_audio}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "faceformer_tf":
         gen_faceformer_teacher_forced(import_reference_models()[0])

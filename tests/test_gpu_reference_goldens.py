@@ -139,3 +139,27 @@ def test_flint_decoder_hip_matches_reference_l2ldecoder(gpu):
     e = np.abs(out.cpu().numpy() - g["flint_z_out"]).max()
     print(f"HIP flint_decoder vs reference L2lDecoder: {e:.2e}")
     assert e < 2e-4
+
+
+@pytest.mark.parametrize("plan", PLANS)
+def test_emote_audio_wrapper_hip_matches_reference(gpu, plan):
+    """int16 raw_audio -> audio_feature through ``TalkingHeadWrapper.forward_audio`` (device-side JOINT normalisation, the
+    processor quirk of AudioEncoders.py:170-178; desired length = T) and the free-length ``ceil`` rule of
+    ``Wav2Vec2Model(length_mode="ceil")`` against EMOTE's own ``Wav2Vec2Encoder._forward`` / ``Wav2Vec2ModelResampled`` run
+    unmodified (tests/golden/emote_audio.npz)."""
+    from avi_talking_amd import ops
+    from avi_talking_amd.weights import make_emote_weights, make_wav2vec2_weights
+    from avi_talking_amd.host.talking_head import TalkingHeadWrapper
+    g = _load("emote_audio.npz")
+    raw = torch.from_numpy(g["raw_audio"].copy()).to(gpu)
+    th = TalkingHeadWrapper(make_wav2vec2_weights(0), make_emote_weights(1), device=gpu, prec=plan, joint_norm=True)
+    s = th.forward_audio({"raw_audio": raw, "samplerate": [16000, 16000]})
+    assert list(s["audio_feature"].shape) == list(g["audio_feature_shape"])
+    e_in = np.abs(s["processed_audio"][:, ::97].cpu().numpy() - g["processed_audio_slice"]).max()
+    e = np.abs(s["audio_feature"][:, :, ::8].cpu().numpy() - g["audio_feature_slice"]).max()
+    n = int(g["free_len_input"])
+    free = th.audio_model(s["processed_audio"][:, :n].contiguous()).last_hidden_state
+    assert list(free.shape) == list(g["free_len_shape"])             # 19 000 samples -> 30 frames (ceil), not 29
+    ef = np.abs(free[:, :, ::8].cpu().numpy() - g["free_len_slice"]).max()
+    print(f"[{plan}] HIP vs EMOTE's own audio wrapper: normalised audio {e_in:.2e}, audio_feature {e:.2e}, free length {ef:.2e}")
+    assert e_in < 5e-6 and e < HIDDEN_GATE[plan] and ef < HIDDEN_GATE[plan]

@@ -309,3 +309,45 @@ def test_oracle_audio_to_coefficients_matches_the_reference_chain(tag):
     e = max(np.abs(out["predicted_exp"].numpy() - g[f"{tag}_exp"]).max(), np.abs(out["predicted_jaw"].numpy() - g[f"{tag}_jaw"]).max())
     print(f"{tag}: oracle vs the reference's wav2vec2 + EMOTE/FLINT chain: hidden {e_hid:.2e} coefficients {e:.2e}")
     assert e_hid < 5e-5 and e < 2e-5
+
+
+def test_audio_normalisation_matches_the_hf_processor_called_as_the_reference_calls_it():
+    """Row A1: the reference hands ``raw_audio.view(B, -1)`` - a 2-D int16 TENSOR - to its HF processor and takes
+    ``proc.input_values[0]`` (inferno/models/temporal/AudioEncoders.py:170-178).  The installed
+    ``transformers.Wav2Vec2FeatureExtractor`` (the class that processor wraps; wav2vec2-base-960h's preprocessor settings)
+    called the same way: a tensor is not a list of clips for it, so the statistics are taken JOINTLY over all B * L samples -
+    ``normalize_audio(joint=True)``; one clip at a time (the reference's batch-1 loop, train_diffusion_prior.py:689) that is
+    the per-clip form the sampling pipeline uses."""
+    from transformers import Wav2Vec2FeatureExtractor
+    fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True,
+                                  return_attention_mask=False)
+    g = torch.Generator().manual_seed(3)
+    raw = (torch.randn(3, 40, 640, generator=g) * torch.tensor([400.0, 3000.0, 9000.0])[:, None, None]).to(torch.int16)
+    flat = raw.view(3, -1)
+    proc = fe(flat, sampling_rate=16000, return_tensors="pt")
+    got = proc.input_values[0]
+    assert got.shape == (3, 40 * 640)
+    assert (got - OW.normalize_audio(flat, joint=True)).abs().max().item() < 2e-6
+    assert (got - OW.normalize_audio(flat, joint=False)).abs().max().item() > 1e-2        # NOT per clip
+    one = fe(flat[1:2], sampling_rate=16000, return_tensors="pt").input_values[0]
+    assert (one - OW.normalize_audio(flat[1:2], joint=False)).abs().max().item() < 2e-6
+
+
+def test_oracle_matches_emotes_own_audio_wrapper():
+    """Rows A1-A4 as EMOTE runs them: the oracle (joint statistics, frame_num = T; and the ``ceil`` length rule without a
+    length) against ``Wav2Vec2Encoder._forward`` / ``Wav2Vec2ModelResampled`` of inferno's AudioEncoders.py run unmodified
+    (tests/golden/emote_audio.npz, make_golden.py::gen_emote_audio)."""
+    g = _load("emote_audio.npz")
+    raw = torch.from_numpy(g["raw_audio"].copy())
+    wa = W.make_wav2vec2_weights(0)
+    B, T = raw.shape[:2]
+    with torch.no_grad():
+        x = OW.normalize_audio(raw.view(B, -1), joint=True)
+        feat = OW.forward(wa, x, frame_num=T, length_mode="ceil")
+        free = OW.forward(wa, x[:, :int(g["free_len_input"])].contiguous(), length_mode="ceil")
+    assert np.abs(x[:, ::97].numpy() - g["processed_audio_slice"]).max() < 2e-6
+    assert list(feat.shape) == list(g["audio_feature_shape"]) and list(free.shape) == list(g["free_len_shape"])
+    e, ef = np.abs(feat[:, :, ::8].numpy() - g["audio_feature_slice"]).max(), np.abs(free[:, :, ::8].numpy() - g["free_len_slice"]).max()
+    print(f"oracle vs EMOTE's Wav2Vec2Encoder._forward: {e:.2e}; free length (ceil rule, {free.shape[1]} frames): {ef:.2e}")
+    assert e < 2e-5 and ef < 2e-5
+    assert OW.forward(wa, x[:, :int(g["free_len_input"])].contiguous(), length_mode="int").shape[1] == free.shape[1] - 1
