@@ -19,88 +19,115 @@
 // block = 128 vertices x all frames of one clip; 512 threads = 128 vertices x 4 frame
 // subgroups, 8 frames in flight per thread (24 accumulators); per-frame coefficients are wave-uniform (scalar loads)
 // and stored frame-group-major [f/8][k][8] by flame_frame_kernel so that one 32-byte scalar load feeds 8 frames.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int NJ = 5, NPF = 36, VT = 128, FG = 8;   // joints, pose features, vertices per block, frames per group
 
-constexpr int SC = 4;   // clips per thread of the shape pass: one basis load feeds SC accumulators
+constexpr int SC = 8;   // clips per thread of the shape pass: one basis load feeds SC accumulators
 
-// grid (ceil(V*3/256), ceil(B/SC)).  The k loop is unrolled by 4 so that four basis loads are in flight per thread.
+// v_shaped[b][i] = v_template[i] + sum_k shape[b][k] shape_basis[k][i], and (the launch's last column of workgroups)
+// jclip[b][15] = j_template + j_shape . shape[b]: the per-clip part of the joint regression, hoisted out of the frames.
+// grid (ceil(V*3/64) + 1, ceil(B/SC)), block 256 = 4 waves: a wave owns a QUARTER of the k range for 64 columns and SC
+// clips (the chain of dependent load rounds is what this small product costs: 300 rows deep it took 44 us, four
+// slices of 75 rows with ten loads in flight take a fifth of that), the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void flame_shape_kernel(const AviFlameBasis fb, const float* __restrict__ shape, int B,
-                                                           float* __restrict__ v_shaped) {
-    const int b0 = blockIdx.y * SC, i = blockIdx.x * blockDim.x + threadIdx.x, n = fb.V * 3;
-    if (i >= n) return;
+                                                           float* __restrict__ v_shaped, float* __restrict__ jclip) {
+    __shared__ float red[4][SC][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = blockIdx.y * SC, n = fb.V * 3;
+    if (blockIdx.x == gridDim.x - 1) {       // rest joints of this row's clips: one wave per clip, lanes split k
+        for (int c = wave; c < SC && b0 + c < B; c += 4) {
+            const float* sp = shape + (long long)(b0 + c) * fb.n_shape;
+            float a[NJ * 3];
+#pragma unroll
+            for (int j = 0; j < NJ * 3; ++j) a[j] = 0.f;
+            for (int k = lane; k < fb.n_shape; k += 64) {
+                const float x = sp[k];
+#pragma unroll
+                for (int j = 0; j < NJ * 3; ++j) a[j] = fmaf(fb.j_shape[(long long)j * fb.n_shape + k], x, a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ * 3; ++j) {
+                const float v = wave_sum_u(a[j]);
+                if (lane == 0) jclip[(b0 + c) * 16 + j] = fb.j_template[j] + v;
+            }
+        }
+        return;
+    }
+    const int i = blockIdx.x * 64 + lane, ic = i < n ? i : n - 1;
     const float* sp[SC];     // wave-uniform rows of `shape` (scalar loads); clips past B repeat the last one
 #pragma unroll
     for (int c = 0; c < SC; ++c) sp[c] = shape + (long long)(b0 + c < B ? b0 + c : B - 1) * fb.n_shape;
     float a[SC];
-    const float t = fb.v_template[i];
 #pragma unroll
-    for (int c = 0; c < SC; ++c) a[c] = t;
-    const float* bp = fb.shape_basis + i;
-    int k = 0;
-    for (; k + 4 <= fb.n_shape; k += 4) {
-        float e[4];
+    for (int c = 0; c < SC; ++c) a[c] = 0.f;
+    const int kq = (fb.n_shape + 3) / 4, kbeg = wave * kq, kend = kbeg + kq < fb.n_shape ? kbeg + kq : fb.n_shape;
+    const float* bp = fb.shape_basis + ic;
+    int k = kbeg;
+    for (; k + 5 <= kend; k += 5) {
+        float e[5];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = bp[(long long)(k + u) * n];
+        for (int u = 0; u < 5; ++u) e[u] = bp[(long long)(k + u) * n];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 5; ++u)
 #pragma unroll
             for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k + u], e[u], a[c]);
     }
-    for (; k < fb.n_shape; ++k) {
+    for (; k < kend; ++k) {
         const float e = bp[(long long)k * n];
 #pragma unroll
         for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k], e, a[c]);
     }
 #pragma unroll
-    for (int c = 0; c < SC; ++c)
-        if (b0 + c < B) v_shaped[(long long)(b0 + c) * n + i] = a[c];
+    for (int c = 0; c < SC; ++c) red[wave][c][lane] = a[c];
+    __syncthreads();
+    if (i >= n) return;
+    const float t = fb.v_template[i];
+    for (int c = wave; c < SC && b0 + c < B; c += 4)
+        v_shaped[(long long)(b0 + c) * n + i] = t + ((red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]));
 }
 
-// jclip[b][15] = j_template + j_shape . shape[b]: the per-clip part of the joint regression, hoisted out of the frames.
-// One wave per clip; lanes split k.
-__global__ __launch_bounds__(64) void flame_joints_kernel(const AviFlameBasis fb, const float* __restrict__ shape,
-                                                           float* __restrict__ jclip) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const float* sp = shape + (long long)b * fb.n_shape;
-    float a[NJ * 3];
+// Per-frame operands.  One wave per frame, four frames per block; j_exp is staged once per block in LDS.
+//   vector-pipe kernel (KP == 0): coefficients fp32 frame-group-major `coef` [F/8][K][8] (K = n_exp + 36), transforms
+//     fp32 `xf` [F][5][12].
+//   matrix-core kernel (KP = 96 | 160): everything in MFMA FRAGMENT order, one block of bytes per (clip, 16-frame tile)
+//     so that the vertices kernel fetches it by LDS-DMA as it lies and every lane reads its 16 bytes conflict-free:
+//       coef tile  [plane hi|lo][ks][fq 4][fr 16][8 bf16]: element (frame fr, basis vector ks*32 + fq*8 + u)
+//       xf tile    [entry e 12][fq 4][fr 16][8 bf16]: slot s = fq*8 + u = joint*6 + term of the transform blend
+//     The blend  T_e = sum_j w_j A_j[e]  is ONE 32-deep bf16 product per entry with fp32-equivalent operands: w and A are
+//     split in three bf16 parts each (w = w1 + w2 + w3 to 2^-24) and the six partial products that matter
+//     (w1 a1, w1 a2, w1 a3, w2 a1, w2 a2, w3 a1; the rest is below 2^-24 of |w a|) take six slots per joint.
+constexpr int XF_TERM_A[6] = {0, 1, 2, 0, 1, 0};    // which part of A a slot holds; the w side holds {0,0,0,1,1,2}
+constexpr int XF_TILE = 12 * 1024;                  // bytes of a transform tile
+
+__device__ __forceinline__ void split3_bf16(float v, uint16_t out[3]) {
 #pragma unroll
-    for (int j = 0; j < NJ * 3; ++j) a[j] = 0.f;
-    for (int k = lane; k < fb.n_shape; k += 64) {
-        const float x = sp[k];
-#pragma unroll
-        for (int j = 0; j < NJ * 3; ++j) a[j] = fmaf(fb.j_shape[(long long)j * fb.n_shape + k], x, a[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ * 3; ++j) {
-        const float v = wave_sum_u(a[j]);
-        if (lane == 0) jclip[b * 16 + j] = fb.j_template[j] + v;
+    for (int i = 0; i < 3; ++i) {
+        const __bf16 h = (__bf16)v;
+        out[i] = __builtin_bit_cast(uint16_t, h);
+        v -= (float)h;
     }
 }
 
-// frame record (floats): coefficients live in `coef` [F/8][K][8] (K = n_exp + 36), transforms in `xf` [F][5][12]
-// one wave per frame, four frames per block
 __global__ __launch_bounds__(256) void flame_frame_kernel(const AviFlameBasis fb, const float* __restrict__ jclip,
                                                            const float* __restrict__ exp, const float* __restrict__ pose,
                                                            int T, int F, float* __restrict__ coef,
                                                            float* __restrict__ xf, int KP) {
-    __shared__ float Js[4][NJ * 3], Rs[4][NJ * 9];
+    __shared__ float Js[4][NJ * 3 + 1], Rs[4][NJ * 9 + 3], Gs[4][NJ * 12 + 4], es[4][128], jes[NJ * 3 * 124];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f = blockIdx.x * 4 + wv < F ? blockIdx.x * 4 + wv : F - 1;   // a spare wave repeats the last frame
-    const int b = f / T;
+    const int b = f / T, t = f - b * T;
     float* J = Js[wv];
     float* R = Rs[wv];
+    float* G = Gs[wv];
     const int K = fb.n_exp + NPF;
     const float* ef = exp + (long long)f * fb.n_exp;
-    if (lane < NJ * 3) {   // joint coordinate `lane`
-        float a = jclip[b * 16 + lane];
-        const float* je = fb.j_exp + (long long)lane * fb.n_exp;
-        for (int k = 0; k < fb.n_exp; ++k) a = fmaf(je[k], ef[k], a);
-        J[lane] = a;
-    }
+    for (int i = threadIdx.x; i < NJ * 3 * fb.n_exp; i += 256) jes[i] = fb.j_exp[i];
+    for (int k = lane; k < fb.n_exp; k += 64) es[wv][k] = ef[k];
     if (lane < NJ) {       // lbs.py:304-335
         const float* p = pose + (long long)f * (NJ * 3) + lane * 3;
         const float x = p[0], y = p[1], z = p[2];
@@ -116,65 +143,97 @@ __global__ __launch_bounds__(256) void flame_frame_kernel(const AviFlameBasis fb
         for (int i = 0; i < 9; ++i) R[lane * 9 + i] = ((i % 4 == 0) ? 1.f : 0.f) + s * k1[i] + c1 * kk[i];
     }
     __syncthreads();
-    // coefficients of the 86 basis vectors: fp32 frame-group-major for the vector-pipe kernel (KP == 0), or split
-    // bf16 planes [F][KP] hi | [F][KP] lo (zero beyond K) for the matrix-core kernel
-    uint16_t* chi = reinterpret_cast<uint16_t*>(coef);
-    uint16_t* clo = chi + (long long)F * KP;
-    for (int k = lane; k < (KP ? KP : K); k += 64) {
-        float v = 0.f;
-        if (k < fb.n_exp) v = ef[k];
-        else if (k < K) {
-            const int q = k - fb.n_exp;   // (R[1 + q/9] - I).flat[q % 9]   (lbs.py:210)
-            v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
-        }
-        if (KP) {
+    {   // joint coordinate c = lane / 4 from four partial sums over k (lanes 60..63 idle)
+        const int c = lane >> 2, q = lane & 3;
+        float a = 0.f;
+        if (c < NJ * 3)
+            for (int k = q; k < fb.n_exp; k += 4) a = fmaf(jes[c * fb.n_exp + k], es[wv][k], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (c < NJ * 3 && q == 0) J[c] = jclip[b * 16 + c] + a;
+    }
+    // coefficients of the K basis vectors
+    const int tile = b * ((T + 15) >> 4) + (t >> 4), fr = t & 15;
+    if (KP) {
+        const int KS = KP >> 5;
+        uint16_t* ct = reinterpret_cast<uint16_t*>(coef) + (long long)tile * (2 * KS * 512);
+        for (int k = lane; k < KP; k += 64) {
+            float v = 0.f;
+            if (k < fb.n_exp) v = es[wv][k];
+            else if (k < K) {
+                const int q = k - fb.n_exp;   // (R[1 + q/9] - I).flat[q % 9]   (lbs.py:210)
+                v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
+            }
             const __bf16 h = (__bf16)v;
             const __bf16 l = (__bf16)(v - (float)h);
-            chi[(long long)f * KP + k] = __builtin_bit_cast(uint16_t, h);
-            clo[(long long)f * KP + k] = __builtin_bit_cast(uint16_t, l);
-        } else {
+            const int o = (k >> 3) * 128 + fr * 8 + (k & 7);      // ((ks*4 + fq)*16 + fr)*8 + u
+            ct[o] = __builtin_bit_cast(uint16_t, h);
+            ct[KS * 512 + o] = __builtin_bit_cast(uint16_t, l);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            float v;
+            if (k < fb.n_exp) v = es[wv][k];
+            else {
+                const int q = k - fb.n_exp;
+                v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
+            }
             coef[((long long)(f / FG) * K + k) * FG + (f % FG)] = v;
         }
     }
+    __syncthreads();       // J is complete (written by other lanes of this wave)
     if (lane == 0) {       // lbs.py:351-410, parents = [-1, 0, 1, 1, 1]
-        float G[NJ][12];   // rows 0..2 of the chained transforms
+        float Gc[NJ][12];  // rows 0..2 of the chained transforms
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int par = j == 0 ? -1 : (j == 1 ? 0 : 1);
-            float t[3];
+            float tr[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] = J[j * 3 + c] - (par >= 0 ? J[par * 3 + c] : 0.f);
+            for (int c = 0; c < 3; ++c) tr[c] = J[j * 3 + c] - (par >= 0 ? J[par * 3 + c] : 0.f);
             if (par < 0) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) G[j][r * 4 + c] = R[j * 9 + r * 3 + c];
-                    G[j][r * 4 + 3] = t[r];
+                    for (int c = 0; c < 3; ++c) Gc[j][r * 4 + c] = R[j * 9 + r * 3 + c];
+                    Gc[j][r * 4 + 3] = tr[r];
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        G[j][r * 4 + c] = G[par][r * 4 + 0] * R[j * 9 + c] + G[par][r * 4 + 1] * R[j * 9 + 3 + c] +
-                                          G[par][r * 4 + 2] * R[j * 9 + 6 + c];
-                    G[j][r * 4 + 3] = G[par][r * 4 + 0] * t[0] + G[par][r * 4 + 1] * t[1] + G[par][r * 4 + 2] * t[2] +
-                                      G[par][r * 4 + 3];
+                        Gc[j][r * 4 + c] = Gc[par][r * 4 + 0] * R[j * 9 + c] + Gc[par][r * 4 + 1] * R[j * 9 + 3 + c] +
+                                           Gc[par][r * 4 + 2] * R[j * 9 + 6 + c];
+                    Gc[j][r * 4 + 3] = Gc[par][r * 4 + 0] * tr[0] + Gc[par][r * 4 + 1] * tr[1] + Gc[par][r * 4 + 2] * tr[2] +
+                                       Gc[par][r * 4 + 3];
                 }
             }
         }
         // relative to the rest pose: translation -= G[:3,:3] . joint
-        float* o = xf + (long long)f * (NJ * 12);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                o[j * 12 + r * 4 + 0] = G[j][r * 4 + 0];
-                o[j * 12 + r * 4 + 1] = G[j][r * 4 + 1];
-                o[j * 12 + r * 4 + 2] = G[j][r * 4 + 2];
-                o[j * 12 + r * 4 + 3] = G[j][r * 4 + 3] - (G[j][r * 4 + 0] * J[j * 3] + G[j][r * 4 + 1] * J[j * 3 + 1] +
-                                                           G[j][r * 4 + 2] * J[j * 3 + 2]);
+                G[j * 12 + r * 4 + 0] = Gc[j][r * 4 + 0];
+                G[j * 12 + r * 4 + 1] = Gc[j][r * 4 + 1];
+                G[j * 12 + r * 4 + 2] = Gc[j][r * 4 + 2];
+                G[j * 12 + r * 4 + 3] = Gc[j][r * 4 + 3] - (Gc[j][r * 4 + 0] * J[j * 3] + Gc[j][r * 4 + 1] * J[j * 3 + 1] +
+                                                             Gc[j][r * 4 + 2] * J[j * 3 + 2]);
             }
+    }
+    __syncthreads();
+    if (KP) {
+        uint16_t* xt = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xf) + (long long)tile * XF_TILE);
+        for (int i = lane; i < 12 * 32; i += 64) {
+            const int e = i >> 5, sl = i & 31, j = sl / 6, term = sl - j * 6;
+            uint16_t parts[3] = {0, 0, 0};
+            if (j < NJ) split3_bf16(G[j * 12 + e], parts);
+            const uint16_t v = j < NJ ? (XF_TERM_A[term] == 0 ? parts[0] : XF_TERM_A[term] == 1 ? parts[1] : parts[2]) : 0;
+            xt[((e * 4 + (sl >> 3)) * 16 + fr) * 8 + (sl & 7)] = v;
+        }
+    } else {
+        float* o = xf + (long long)f * (NJ * 12);
+        for (int i = lane; i < NJ * 12; i += 64) o[i] = G[i];
     }
 }
 
@@ -259,65 +318,65 @@ __global__ __launch_bounds__(256) void flame_pack_basis_kernel(const AviFlameBas
     lo[i] = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
 }
 
-// grid (ceil(V/64), B), block 256: wave w owns vertices [vt*16, vt*16+16), vt = 4*blockIdx.x + w, and walks the frames of
-// clip blockIdx.y in tiles of 16.  MFMA operand roles as in gemm.hip: first operand = rows of the "n" matrix (vertices),
-// second = rows of the "m" matrix (frames); lane (fr, fq) receives D[frame f0+fr][vertex vt*16 + fq*4 + 0..3] per
-// coordinate plane.  The per-tile operands of the four waves (they work on the SAME 16 frames of the clip) are
-// fetched once per workgroup by LDS-DMA, one frame tile ahead: the coefficient planes (2 x 32 KP bytes) and the 16 x 240 B
-// of transforms of tile t+1 are requested right after the barrier that opens tile t and land under its MFMAs, skinning
-// and stores (with per-wave global loads instead, every wave waited out the L2 latency twice per tile: 329 -> 265 us).
+// One workgroup (256 threads) per (64 vertices, clip): wave w owns vertices [vt*16, vt*16+16), vt = 4*bx + w, and walks
+// the clip's frames in tiles of 16.  MFMA operand roles as in gemm.hip: first operand = rows of the "n" matrix (vertices),
+// second = rows of the "m" matrix (frames); lane (fr, fq) receives D[frame f0+fr][vertex vt*16 + fq*4 + 0..3].
+//   blend      27 (KS = 3) products 16x16x32 in 3-term split bf16 against the basis fragments resident in registers,
+//              accumulators started at the clip's shaped template;
+//   transforms 12 products 16x16x32 (one per entry of the 3 x 4 blend of the five joint transforms, see
+//              flame_frame_kernel) against the wave's skinning-weight fragment - the 240 multiply-adds per lane this
+//              replaces were what the kernel's time went on (vector pipe 4 cycles each, 265 -> 223 us with an exact-fp32
+//              16x16x4 form, this form halves the matrix cycles again and needs no accumulator set-up);
+//   skinning   3 fused multiply-adds per output on the accumulators; the 48 bytes per lane leave through an LDS slab so
+//              that 12 consecutive lanes write one frame's 192 bytes.
+// The operands of a tile (coefficient planes 2 KS KiB + transform planes 12 KiB, both in fragment order) are fetched once
+// per workgroup by LDS-DMA, one tile ahead: requested right after the barrier that opens tile t, they land under its
+// arithmetic and stores.
 //   vmcnt: the DMA requests of a wave are older than the three output stores of the tile, so `s_waitcnt vmcnt(3)` at
 //   the top of the next tile means "my DMA pieces have landed"; the barrier that follows makes that true for all waves
 //   and also orders the previous tile's LDS reads before the buffer is refilled (two buffers, one barrier per tile).
+// Workgroup numbering is XCD-aware: ids are dealt round-robin to the 8 XCDs (each with its own L2), and a frame's row of
+// the output is only 4-byte aligned (V*3 floats), so neighbouring vertex groups share cache lines; numbered naively the
+// two halves of such a line are written from two L2s and reach memory as two partial writes - the store pattern ALONE then
+// takes 123-142 us for the 482 MB of config[1] against 87-116 us with neighbours on one XCD (`scripts/probe/
+// flame_store_probe.hip`; 74-93 us if rows could be padded to 64 bytes, which the reference's contiguous layout forbids).
 typedef __attribute__((address_space(3))) void flame_lds_void;
 typedef const __attribute__((address_space(1))) void flame_gbl_void;
 
-template <int KS>
-__global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kernel(const AviFlameBasis fb,
+template <int KS, int OCC>
+__global__ __launch_bounds__(256, OCC) void flame_vertices_mfma_kernel(const AviFlameBasis fb,
                                                                    const float* __restrict__ v_shaped,
-                                                                   const uint16_t* __restrict__ chi,
-                                                                   const uint16_t* __restrict__ clo,
-                                                                   const float* __restrict__ xf, int T, int Vp,
-                                                                   float* __restrict__ verts) {
+                                                                   const char* __restrict__ coef_tiles,
+                                                                   const char* __restrict__ xf_tiles, int T, int Vp, int nx,
+                                                                   int total, float* __restrict__ verts) {
     constexpr int KP = KS * 32, SLAB_ROW = 52;
-    constexpr int CROW = KP * 2;                       // bytes of one frame's coefficients in a plane (192 / 320)
-    constexpr int CPL = 16 * CROW;                     // one plane of a 16-frame tile = KS KiB
-    constexpr int XROW = NJ * 12 * 4;                  // 240 B of transforms per frame
-    constexpr int BUF = 2 * CPL + 4096;                // [coef hi | coef lo | transforms (3840 B used)]
-    constexpr int NCH = 2 * KS + 4;                    // 1-KiB DMA pieces per tile
+    constexpr int CT = 2 * KS * 1024;                  // bytes of a coefficient tile (hi | lo)
+    constexpr int BUF = CT + XF_TILE;
+    constexpr int NCH = 2 * KS + 12;                   // 1-KiB DMA pieces per tile
     __shared__ __attribute__((aligned(16))) char stage[2 * BUF];
     __shared__ __attribute__((aligned(16))) float slabs[4 * 16 * SLAB_ROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int b = blockIdx.y;
-    const int vt_raw = blockIdx.x * 4 + wave;
+    // the launch holds 8 * ceil(total / 8) workgroups: id % 8 is the XCD, which takes a contiguous range of (clip, group)
+    const int per = gridDim.x >> 3, L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (L >= total) return;
+    const int b = L / nx, bx = L - b * nx;
+    const int vt_raw = bx * 4 + wave;
     const bool live = vt_raw * 16 < fb.V;              // wave-uniform; a spare wave still fetches and synchronises
     const int vt = live ? vt_raw : 0;
-    const int fbeg = b * T, fend = fbeg + T;
+    const int fbeg = b * T, fend = fbeg + T, ntile = (T + 15) >> 4;
+    const char* ctile = coef_tiles + (long long)b * ntile * CT;
+    const char* xtile = xf_tiles + (long long)b * ntile * XF_TILE;
 
-    // piece c of a tile: 64 lanes x 16 B of [coef hi | coef lo | transforms]; rows past the clip re-read its last frame
-    auto issue = [&](int f0, int buf) __attribute__((always_inline)) {
+    auto issue = [&](int ti, int buf) __attribute__((always_inline)) {
         for (int c = wave; c < NCH; c += 4) {
-            const char* base;
-            int row_bytes, o;
-            if (c < 2 * KS) {
-                base = reinterpret_cast<const char*>(c < KS ? chi : clo);
-                row_bytes = CROW;
-                o = (c < KS ? c : c - KS) * 1024 + lane * 16;
-            } else {
-                base = reinterpret_cast<const char*>(xf);
-                row_bytes = XROW;
-                o = (c - 2 * KS) * 1024 + lane * 16;
-            }
-            const int rf = o / row_bytes, within = o - rf * row_bytes;
-            const int f = f0 + rf < fend ? f0 + rf : fend - 1;
-            const char* src = base + (long long)f * row_bytes + within;
-            char* dst = stage + buf * BUF + (c < 2 * KS ? c * 1024 : 2 * CPL + (c - 2 * KS) * 1024);
-            __builtin_amdgcn_global_load_lds((flame_gbl_void*)src, (flame_lds_void*)dst, 16, 0, 0);
+            const char* src = c < 2 * KS ? ctile + (long long)ti * CT + c * 1024 : xtile + (long long)ti * XF_TILE + (c - 2 * KS) * 1024;
+            __builtin_amdgcn_global_load_lds((flame_gbl_void*)(src + lane * 16), (flame_lds_void*)(stage + buf * BUF + c * 1024), 16,
+                                             0, 0);
         }
     };
-    issue(fbeg, 0);
+    issue(0, 0);
 
     bf16x8 bh[3][KS], bl[3][KS];
 #pragma unroll
@@ -328,34 +387,44 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
             bh[c][ks] = *reinterpret_cast<const bf16x8*>(fb.basis_hi + o);
             bl[c][ks] = *reinterpret_cast<const bf16x8*>(fb.basis_lo + o);
         }
+    // skinning-weight fragment: slot s = fq*8 + u = joint*6 + term holds part {0,0,0,1,1,2}[term] of w[vertex fr][joint]
+    bf16x8 wf;
+    {
+        const float* wr = fb.lbs_weights + (long long)(vt * 16 + fr < fb.V ? vt * 16 + fr : fb.V - 1) * NJ;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = fq * 8 + u, j = sl / 6, term = sl - j * 6;
+            uint16_t parts[3] = {0, 0, 0};
+            if (j < NJ) split3_bf16(wr[j], parts);
+            const uint16_t v = j < NJ ? (term < 3 ? parts[0] : term < 5 ? parts[1] : parts[2]) : 0;
+            wf[u] = __builtin_bit_cast(__bf16, v);
+        }
+    }
     const int vb = vt * 16 + fq * 4, n3 = fb.V * 3;
-    float w[4][NJ], vs[4][3];
+    f32x4 vs[3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int vi = vb + j < fb.V ? vb + j : fb.V - 1;
 #pragma unroll
-        for (int q = 0; q < NJ; ++q) w[j][q] = fb.lbs_weights[(long long)vi * NJ + q];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) vs[j][c] = v_shaped[(long long)b * n3 + vi * 3 + c];
+        for (int c = 0; c < 3; ++c) vs[c][j] = v_shaped[(long long)b * n3 + vi * 3 + c];
     }
     const bool full = vt * 16 + 16 <= fb.V;            // wave-uniform
     int buf = 0;
-    for (int f0 = fbeg; f0 < fend; f0 += 16, buf ^= 1) {
+    for (int ti = 0; ti < ntile; ++ti, buf ^= 1) {
+        const int f0 = fbeg + ti * 16;
         // my pieces of this tile have landed (only the previous tile's three output stores may still be in flight)
-        if (live && full && f0 != fbeg) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (live && full && ti) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (f0 + 16 < fend) issue(f0 + 16, buf ^ 1);
+        if (ti + 1 < ntile) issue(ti + 1, buf ^ 1);
         if (!live) continue;
         const char* sb = stage + buf * BUF;
-        f32x4 acc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[3] = {vs[0], vs[1], vs[2]};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int o = fr * CROW + (ks * 4 + fq) * 16;
+            const int o = (ks * 4 + fq) * 256 + fr * 16;
             const bf16x8 ch = *reinterpret_cast<const bf16x8*>(sb + o);
-            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(sb + CPL + o);
+            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(sb + KS * 1024 + o);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[c][ks], ch, acc[c], 0, 0, 0);
@@ -363,28 +432,19 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[c][ks], ch, acc[c], 0, 0, 0);
             }
         }
-        const f32x4* ap = reinterpret_cast<const f32x4*>(sb + 2 * CPL + fr * XROW);
-        float px[4], py[4], pz[4], o[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            px[j] = vs[j][0] + acc[0][j];
-            py[j] = vs[j][1] + acc[1][j];
-            pz[j] = vs[j][2] + acc[2][j];
-        }
+        const char* xb = sb + CT + fq * 256 + fr * 16;
+        float o[12];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            f32x4 a[NJ];
+            f32x4 t[4];                                   // t[e][j]: entry e of row r of the blended transform, vertex j
 #pragma unroll
-            for (int q = 0; q < NJ; ++q) a[q] = ap[q * 3 + r];
+            for (int e = 0; e < 4; ++e)
+                t[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *reinterpret_cast<const bf16x8*>(xb + (r * 4 + e) * 1024),
+                                                               (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 t = a[0] * w[j][0];
-#pragma unroll
-                for (int q = 1; q < NJ; ++q) t += a[q] * w[j][q];
-                o[j * 3 + r] = t[0] * px[j] + t[1] * py[j] + t[2] * pz[j] + t[3];
-            }
+            for (int j = 0; j < 4; ++j)
+                o[j * 3 + r] = fmaf(t[2][j], acc[2][j], fmaf(t[1][j], acc[1][j], fmaf(t[0][j], acc[0][j], t[3][j])));
         }
-        const int f = f0 + fr;
         if (full) {
             float* slab = slabs + wave * (16 * SLAB_ROW);
 #pragma unroll
@@ -411,8 +471,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 2 : 1) void flame_vertices_mfma_kern
                 if (ff < 0) val[i] = *reinterpret_cast<const f32x4*>(slab + 0 * SLAB_ROW + piece[i] * 4);
                 *reinterpret_cast<f32x4u*>(dst) = val[i];
             }
-        } else if (f < fend) {
-            float* op = verts + ((long long)f * fb.V + vb) * 3;
+        } else if (f0 + fr < fend) {
+            float* op = verts + ((long long)(f0 + fr) * fb.V + vb) * 3;
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 if (vb + i / 3 < fb.V) op[i] = o[i];
@@ -427,28 +487,38 @@ extern "C" int avi_flame_vertices(const AviFlameBasis* fbp, const float* shape, 
     if (!fbp || !shape || !exp || !pose || !v_shaped || !coef || !xf || !verts || B <= 0 || T <= 0) return AVI_EINVAL;
     const AviFlameBasis& fb = *fbp;
     if (!fb.v_template || !fb.shape_basis || !fb.frame_basis || !fb.j_template || !fb.j_shape || !fb.j_exp ||
-        !fb.lbs_weights || fb.V <= 0 || fb.n_shape <= 0 || fb.n_exp <= 0)
+        !fb.lbs_weights || fb.V <= 0 || fb.n_shape <= 0 || fb.n_exp <= 0 || fb.n_exp > 124)
         return AVI_EINVAL;
     const int K = fb.n_exp + NPF;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int F = B * T;
-    float* jclip = xf + (long long)F * (NJ * 12);   // [B][16] behind the transforms
-    hipLaunchKernelGGL(flame_shape_kernel, dim3((fb.V * 3 + 255) / 256, (B + SC - 1) / SC), dim3(256), 0, s, fb, shape, B,
-                       v_shaped);
-    hipLaunchKernelGGL(flame_joints_kernel, dim3(B), dim3(64), 0, s, fb, shape, jclip);
+    const int F = B * T, ntile = (T + 15) / 16;
+    const long long xf_floats = (long long)F * (NJ * 12) > (long long)B * ntile * (XF_TILE / 4) ? (long long)F * (NJ * 12)
+                                                                                                : (long long)B * ntile * (XF_TILE / 4);
+    float* jclip = xf + xf_floats;                  // [B][16] behind the transforms
+    hipLaunchKernelGGL(flame_shape_kernel, dim3((fb.V * 3 + 63) / 64 + 1, (B + SC - 1) / SC), dim3(256), 0, s, fb, shape, B,
+                       v_shaped, jclip);
     if (fb.basis_hi && fb.basis_lo && K <= 160) {   // matrix-core path
         if ((reinterpret_cast<uintptr_t>(fb.basis_hi) | reinterpret_cast<uintptr_t>(fb.basis_lo) |
              reinterpret_cast<uintptr_t>(coef) | reinterpret_cast<uintptr_t>(xf)) & 15)
             return AVI_EINVAL;
         const int KS = K <= 96 ? 3 : 5, KP = KS * 32, Vp = (fb.V + 15) / 16 * 16;
         hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, KP);
-        const uint16_t* chi = reinterpret_cast<const uint16_t*>(coef);
-        const uint16_t* clo = chi + (long long)F * KP;
-        const dim3 grid((Vp / 16 + 3) / 4, B);
-        if (KS == 3)
-            hipLaunchKernelGGL(flame_vertices_mfma_kernel<3>, grid, dim3(256), 0, s, fb, v_shaped, chi, clo, xf, T, Vp, verts);
+        const int nx = (Vp / 16 + 3) / 4;
+        const long long total = (long long)nx * B;
+        if (total > (1ll << 30)) return AVI_EINVAL;
+        const dim3 grid((unsigned)((total + 7) / 8 * 8));
+        const char* ct = reinterpret_cast<const char*>(coef);
+        const char* xt = reinterpret_cast<const char*>(xf);
+        static const int occ = getenv("AVI_FLAME_OCC") ? atoi(getenv("AVI_FLAME_OCC")) : 3;
+        if (KS == 3 && occ == 3)
+            hipLaunchKernelGGL((flame_vertices_mfma_kernel<3, 3>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
+                               (int)total, verts);
+        else if (KS == 3)
+            hipLaunchKernelGGL((flame_vertices_mfma_kernel<3, 2>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
+                               (int)total, verts);
         else
-            hipLaunchKernelGGL(flame_vertices_mfma_kernel<5>, grid, dim3(256), 0, s, fb, v_shaped, chi, clo, xf, T, Vp, verts);
+            hipLaunchKernelGGL((flame_vertices_mfma_kernel<5, 2>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
+                               (int)total, verts);
         return avi_launch_status();
     }
     const int smem = K * 3 * VT * (int)sizeof(float);

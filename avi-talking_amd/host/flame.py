@@ -63,8 +63,9 @@ class FLAME:
         shape, exp, pose15 = f(shape), f(exp), f(pose15)
         F, K = B * T, self.n_exp + 36
         vsh = torch.empty((B, self.V * 3), dtype=torch.float32, device=self.device)
-        coef = torch.empty(((F + 7) // 8 * 8 * max(K, 160),), dtype=torch.float32, device=self.device)
-        xf = torch.empty((F * 60 + B * 16,), dtype=torch.float32, device=self.device)
+        tiles = B * ((T + 15) // 16)                      # matrix-core path: operands in 16-frame fragment tiles
+        coef = torch.empty((max((F + 7) // 8 * 8 * max(K, 160), tiles * 2560),), dtype=torch.float32, device=self.device)
+        xf = torch.empty((max(F * 60, tiles * 3072) + B * 16,), dtype=torch.float32, device=self.device)
         out = torch.empty((B, T, self.V, 3), dtype=torch.float32, device=self.device)
         L.check(L.load().avi_flame_vertices(C.byref(self.fb), shape.data_ptr(), exp.data_ptr(), pose15.data_ptr(), B, T,
                                             vsh.data_ptr(), coef.data_ptr(), xf.data_ptr(), out.data_ptr(),

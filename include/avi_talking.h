@@ -585,8 +585,9 @@ typedef struct AviFlameBasis {
     const uint16_t* basis_lo;
 } AviFlameBasis;
 /* shape [B][n_shape] (one per clip), exp [B*T][n_exp], pose [B*T][15] = axis-angle of (global, neck, jaw, eye_l, eye_r)
- * -> verts [B*T][V][3].  Scratch (16-byte aligned): v_shaped B*V*3 floats, coef ceil(B*T/8)*8*160 floats (covers both
- * kernels), xf B*T*60 + B*16 floats (per-frame transforms, then the per-clip rest joints). */
+ * -> verts [B*T][V][3].  Scratch (16-byte aligned; tiles = B * ceil(T/16): the matrix-core kernel takes its per-frame
+ * operands in 16-frame fragment tiles per clip): v_shaped B*V*3 floats, coef max(ceil(B*T/8)*8*160, tiles*2560) floats,
+ * xf max(B*T*60, tiles*3072) + B*16 floats (per-frame transforms, then the per-clip rest joints).  n_exp <= 124. */
 int avi_flame_vertices(const AviFlameBasis* fb, const float* shape, const float* exp, const float* pose, int B, int T,
                        float* v_shaped, float* coef, float* xf, float* verts, void* stream);
 /* Fill the optional basis planes of `fb` (see AviFlameBasis): hi / lo hold 3*Vp*KP uint16 each.  Once per model. */
