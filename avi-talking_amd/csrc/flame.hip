@@ -27,71 +27,11 @@ namespace {
 
 constexpr int NJ = 5, NPF = 36, VT = 128, FG = 8;   // joints, pose features, vertices per block, frames per group
 
-constexpr int SC = 8;   // clips per thread of the shape pass: one basis load feeds SC accumulators
-
-// v_shaped[b][i] = v_template[i] + sum_k shape[b][k] shape_basis[k][i], and (the launch's last column of workgroups)
-// jclip[b][15] = j_template + j_shape . shape[b]: the per-clip part of the joint regression, hoisted out of the frames.
-// grid (ceil(V*3/64) + 1, ceil(B/SC)), block 256 = 4 waves: a wave owns a QUARTER of the k range for 64 columns and SC
-// clips (the chain of dependent load rounds is what this small product costs: 300 rows deep it took 44 us, four
-// slices of 75 rows with ten loads in flight take a fifth of that), the four partial sums meet in LDS.
-__global__ __launch_bounds__(256) void flame_shape_kernel(const AviFlameBasis fb, const float* __restrict__ shape, int B,
-                                                           float* __restrict__ v_shaped, float* __restrict__ jclip) {
-    __shared__ float red[4][SC][64];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b0 = blockIdx.y * SC, n = fb.V * 3;
-    if (blockIdx.x == gridDim.x - 1) {       // rest joints of this row's clips: one wave per clip, lanes split k
-        for (int c = wave; c < SC && b0 + c < B; c += 4) {
-            const float* sp = shape + (long long)(b0 + c) * fb.n_shape;
-            float a[NJ * 3];
-#pragma unroll
-            for (int j = 0; j < NJ * 3; ++j) a[j] = 0.f;
-            for (int k = lane; k < fb.n_shape; k += 64) {
-                const float x = sp[k];
-#pragma unroll
-                for (int j = 0; j < NJ * 3; ++j) a[j] = fmaf(fb.j_shape[(long long)j * fb.n_shape + k], x, a[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ * 3; ++j) {
-                const float v = wave_sum_u(a[j]);
-                if (lane == 0) jclip[(b0 + c) * 16 + j] = fb.j_template[j] + v;
-            }
-        }
-        return;
-    }
-    const int i = blockIdx.x * 64 + lane, ic = i < n ? i : n - 1;
-    const float* sp[SC];     // wave-uniform rows of `shape` (scalar loads); clips past B repeat the last one
-#pragma unroll
-    for (int c = 0; c < SC; ++c) sp[c] = shape + (long long)(b0 + c < B ? b0 + c : B - 1) * fb.n_shape;
-    float a[SC];
-#pragma unroll
-    for (int c = 0; c < SC; ++c) a[c] = 0.f;
-    const int kq = (fb.n_shape + 3) / 4, kbeg = wave * kq, kend = kbeg + kq < fb.n_shape ? kbeg + kq : fb.n_shape;
-    const float* bp = fb.shape_basis + ic;
-    int k = kbeg;
-    for (; k + 5 <= kend; k += 5) {
-        float e[5];
-#pragma unroll
-        for (int u = 0; u < 5; ++u) e[u] = bp[(long long)(k + u) * n];
-#pragma unroll
-        for (int u = 0; u < 5; ++u)
-#pragma unroll
-            for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k + u], e[u], a[c]);
-    }
-    for (; k < kend; ++k) {
-        const float e = bp[(long long)k * n];
-#pragma unroll
-        for (int c = 0; c < SC; ++c) a[c] = fmaf(sp[c][k], e, a[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < SC; ++c) red[wave][c][lane] = a[c];
-    __syncthreads();
-    if (i >= n) return;
-    const float t = fb.v_template[i];
-    for (int c = wave; c < SC && b0 + c < B; c += 4)
-        v_shaped[(long long)(b0 + c) * n + i] = t + ((red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]));
-}
-
-// Per-frame operands.  One wave per frame, four frames per block; j_exp is staged once per block in LDS.
+// ---- preparation: ONE launch, two kinds of workgroups (256 threads) -----------------------------------------------------
+// (as three launches - shape, rest joints, frames - the preparation took 77 us of a 346-us pass at config[1] size: each was
+// a chain of dependent load rounds a few workgroups deep; the two kinds below do not depend on each other)
+//
+// "tile" workgroups, one per (clip, 16 frames): everything the vertices kernels need per FRAME.
 //   vector-pipe kernel (KP == 0): coefficients fp32 frame-group-major `coef` [F/8][K][8] (K = n_exp + 36), transforms
 //     fp32 `xf` [F][5][12].
 //   matrix-core kernel (KP = 96 | 160): everything in MFMA FRAGMENT order, one block of bytes per (clip, 16-frame tile)
@@ -101,8 +41,13 @@ __global__ __launch_bounds__(256) void flame_shape_kernel(const AviFlameBasis fb
 //     The blend  T_e = sum_j w_j A_j[e]  is ONE 32-deep bf16 product per entry with fp32-equivalent operands: w and A are
 //     split in three bf16 parts each (w = w1 + w2 + w3 to 2^-24) and the six partial products that matter
 //     (w1 a1, w1 a2, w1 a3, w2 a1, w2 a2, w3 a1; the rest is below 2^-24 of |w a|) take six slots per joint.
+//     Frames past the end of the clip (its last tile) repeat the clip's last frame.
+// "shape" workgroups, one per (32 columns of V*3, 32 clips): v_shaped = v_template + shape . shape_basis in exact fp32 on
+//   the matrix cores (v_mfma_f32_16x16x4_f32); a wave owns a quarter of the k range (the chain of dependent load rounds is
+//   what this small product costs: 300 rows deep on the vector pipe it took 44 us), the four partial sums meet in LDS.
 constexpr int XF_TERM_A[6] = {0, 1, 2, 0, 1, 0};    // which part of A a slot holds; the w side holds {0,0,0,1,1,2}
 constexpr int XF_TILE = 12 * 1024;                  // bytes of a transform tile
+constexpr int MAX_EXP = 124;
 
 __device__ __forceinline__ void split3_bf16(float v, uint16_t out[3]) {
 #pragma unroll
@@ -113,76 +58,92 @@ __device__ __forceinline__ void split3_bf16(float v, uint16_t out[3]) {
     }
 }
 
-__global__ __launch_bounds__(256) void flame_frame_kernel(const AviFlameBasis fb, const float* __restrict__ jclip,
-                                                           const float* __restrict__ exp, const float* __restrict__ pose,
-                                                           int T, int F, float* __restrict__ coef,
-                                                           float* __restrict__ xf, int KP) {
-    __shared__ float Js[4][NJ * 3 + 1], Rs[4][NJ * 9 + 3], Gs[4][NJ * 12 + 4], es[4][128], jes[NJ * 3 * 124];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + wv < F ? blockIdx.x * 4 + wv : F - 1;   // a spare wave repeats the last frame
-    const int b = f / T, t = f - b * T;
-    float* J = Js[wv];
-    float* R = Rs[wv];
-    float* G = Gs[wv];
-    const int K = fb.n_exp + NPF;
-    const float* ef = exp + (long long)f * fb.n_exp;
-    for (int i = threadIdx.x; i < NJ * 3 * fb.n_exp; i += 256) jes[i] = fb.j_exp[i];
-    for (int k = lane; k < fb.n_exp; k += 64) es[wv][k] = ef[k];
-    if (lane < NJ) {       // lbs.py:304-335
-        const float* p = pose + (long long)f * (NJ * 3) + lane * 3;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of V*3 floats are dword aligned only
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+
+struct PrepTileLds {
+    float jes[NJ * 3 * MAX_EXP], es[16][128], Rs[16][NJ * 9 + 3], Js[16][16], Gs[16][NJ * 12 + 4], jc[16];
+};
+struct PrepShapeLds {
+    f32x4 red[4][4][64];
+};
+union PrepLds {
+    PrepTileLds t;
+    PrepShapeLds s;
+};
+
+__device__ __forceinline__ void prep_tile_block(const AviFlameBasis& fb, const float* __restrict__ shape,
+                                                const float* __restrict__ exp, const float* __restrict__ pose, int T, int b,
+                                                int ti, float* __restrict__ coef, float* __restrict__ xf, int KP,
+                                                PrepTileLds& L) {
+    const int tid = threadIdx.x, fr = tid >> 4, sub = tid & 15;
+    const int K = fb.n_exp + NPF, nt = T - ti * 16 < 16 ? T - ti * 16 : 16;       // frames of this tile
+    const long long fbase = (long long)b * T + ti * 16;
+    const long long f = fbase + (fr < nt ? fr : nt - 1);
+    // Every global value this workgroup needs is requested before the first one is used (loops of load -> store pairs
+    // wait out one memory round trip per iteration: 26 of them made this the longest kernel of the preparation).
+    {
+        float v[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {       // j_exp: 15 n_exp <= 1 860 values; 16 frames of expression: <= 1 984
+            const int i = tid + u * 256, r = i / fb.n_exp, k = i - r * fb.n_exp;
+            v[u] = i < NJ * 3 * fb.n_exp ? fb.j_exp[i] : 0.f;
+            w[u] = i < 16 * fb.n_exp ? exp[(fbase + (r < nt ? r : nt - 1)) * fb.n_exp + k] : 0.f;
+        }
+        // rest joints of the clip, j_template + j_shape . shape[b]: a thread takes shape[k] against all 15 rows
+        float a[NJ * 3];
+#pragma unroll
+        for (int c = 0; c < NJ * 3; ++c) a[c] = 0.f;
+        for (int k0 = 0; k0 < fb.n_shape; k0 += 256) {
+            const int k = k0 + tid, kk = k < fb.n_shape ? k : fb.n_shape - 1;
+            const float x = k < fb.n_shape ? shape[(long long)b * fb.n_shape + kk] : 0.f;
+            float js[NJ * 3];
+#pragma unroll
+            for (int c = 0; c < NJ * 3; ++c) js[c] = fb.j_shape[(long long)c * fb.n_shape + kk];
+#pragma unroll
+            for (int c = 0; c < NJ * 3; ++c) a[c] = fmaf(js[c], x, a[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256, r = i / fb.n_exp, k = i - r * fb.n_exp;
+            if (i < NJ * 3 * fb.n_exp) L.jes[i] = v[u];
+            if (i < 16 * fb.n_exp) L.es[r][k] = w[u];
+        }
+#pragma unroll
+        for (int c = 0; c < NJ * 3; ++c) {
+            const float t = wave_sum_u(a[c]);
+            if ((tid & 63) == 0) L.Js[tid >> 6][c] = t;      // Js is free until the joints are formed below
+        }
+    }
+    if (sub < NJ) {       // lbs.py:304-335
+        const float* p = pose + f * (NJ * 3) + sub * 3;
         const float x = p[0], y = p[1], z = p[2];
         const float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
         const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
         const float rx = x / angle, ry = y / angle, rz = z / angle;
-        const float s = sinf(angle), c1 = 1.f - cosf(angle);
+        const float sn = sinf(angle), c1 = 1.f - cosf(angle);
         // K = [[0,-rz,ry],[rz,0,-rx],[-ry,rx,0]];  R = I + s K + (1-c) K.K
         const float kk[9] = {-(ry * ry + rz * rz), rx * ry, rx * rz, rx * ry, -(rx * rx + rz * rz), ry * rz,
                              rx * rz, ry * rz, -(rx * rx + ry * ry)};
         const float k1[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[lane * 9 + i] = ((i % 4 == 0) ? 1.f : 0.f) + s * k1[i] + c1 * kk[i];
+        for (int i = 0; i < 9; ++i) L.Rs[fr][sub * 9 + i] = ((i % 4 == 0) ? 1.f : 0.f) + sn * k1[i] + c1 * kk[i];
     }
     __syncthreads();
-    {   // joint coordinate c = lane / 4 from four partial sums over k (lanes 60..63 idle)
-        const int c = lane >> 2, q = lane & 3;
-        float a = 0.f;
-        if (c < NJ * 3)
-            for (int k = q; k < fb.n_exp; k += 4) a = fmaf(jes[c * fb.n_exp + k], es[wv][k], a);
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        if (c < NJ * 3 && q == 0) J[c] = jclip[b * 16 + c] + a;
+    if (tid < NJ * 3) L.jc[tid] = fb.j_template[tid] + ((L.Js[0][tid] + L.Js[1][tid]) + (L.Js[2][tid] + L.Js[3][tid]));
+    __syncthreads();
+    if (sub < NJ * 3) {   // joints of frame fr: rest joints + j_exp . exp
+        float a = L.jc[sub];
+        const float* je = L.jes + sub * fb.n_exp;
+        for (int k = 0; k < fb.n_exp; ++k) a = fmaf(je[k], L.es[fr][k], a);
+        L.Js[fr][sub] = a;
     }
-    // coefficients of the K basis vectors
-    const int tile = b * ((T + 15) >> 4) + (t >> 4), fr = t & 15;
-    if (KP) {
-        const int KS = KP >> 5;
-        uint16_t* ct = reinterpret_cast<uint16_t*>(coef) + (long long)tile * (2 * KS * 512);
-        for (int k = lane; k < KP; k += 64) {
-            float v = 0.f;
-            if (k < fb.n_exp) v = es[wv][k];
-            else if (k < K) {
-                const int q = k - fb.n_exp;   // (R[1 + q/9] - I).flat[q % 9]   (lbs.py:210)
-                v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
-            }
-            const __bf16 h = (__bf16)v;
-            const __bf16 l = (__bf16)(v - (float)h);
-            const int o = (k >> 3) * 128 + fr * 8 + (k & 7);      // ((ks*4 + fq)*16 + fr)*8 + u
-            ct[o] = __builtin_bit_cast(uint16_t, h);
-            ct[KS * 512 + o] = __builtin_bit_cast(uint16_t, l);
-        }
-    } else {
-        for (int k = lane; k < K; k += 64) {
-            float v;
-            if (k < fb.n_exp) v = es[wv][k];
-            else {
-                const int q = k - fb.n_exp;
-                v = R[9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
-            }
-            coef[((long long)(f / FG) * K + k) * FG + (f % FG)] = v;
-        }
-    }
-    __syncthreads();       // J is complete (written by other lanes of this wave)
-    if (lane == 0) {       // lbs.py:351-410, parents = [-1, 0, 1, 1, 1]
+    __syncthreads();
+    if (sub == 0) {       // lbs.py:351-410, parents = [-1, 0, 1, 1, 1]
+        const float* R = L.Rs[fr];
+        const float* J = L.Js[fr];
+        float* G = L.Gs[fr];
         float Gc[NJ][12];  // rows 0..2 of the chained transforms
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -222,18 +183,122 @@ __global__ __launch_bounds__(256) void flame_frame_kernel(const AviFlameBasis fb
             }
     }
     __syncthreads();
+    // coefficient k of frame r: expression, then (R[1 + q/9] - I).flat[q % 9]  (lbs.py:210), zero padding
+    auto coefficient = [&](int r, int k) __attribute__((always_inline)) {
+        if (k < fb.n_exp) return L.es[r][k];
+        if (k >= K) return 0.f;
+        const int q = k - fb.n_exp;
+        return L.Rs[r][9 + q] - ((q % 9) % 4 == 0 ? 1.f : 0.f);
+    };
     if (KP) {
-        uint16_t* xt = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(xf) + (long long)tile * XF_TILE);
-        for (int i = lane; i < 12 * 32; i += 64) {
-            const int e = i >> 5, sl = i & 31, j = sl / 6, term = sl - j * 6;
-            uint16_t parts[3] = {0, 0, 0};
-            if (j < NJ) split3_bf16(G[j * 12 + e], parts);
-            const uint16_t v = j < NJ ? (XF_TERM_A[term] == 0 ? parts[0] : XF_TERM_A[term] == 1 ? parts[1] : parts[2]) : 0;
-            xt[((e * 4 + (sl >> 3)) * 16 + fr) * 8 + (sl & 7)] = v;
+        const int KS = KP >> 5, tile = b * ((T + 15) >> 4) + ti;
+        char* ct = reinterpret_cast<char*>(coef) + (long long)tile * (2 * KS * 1024);
+        for (int ch = tid; ch < KS * 64; ch += 256) {        // chunk ((ks*4 + fq)*16 + r): 8 coefficients of frame r
+            const int r = ch & 15, k0 = (ch >> 4) * 8;
+            u16x8 hi, lo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = coefficient(r, k0 + u);
+                const __bf16 h = (__bf16)v;
+                hi[u] = __builtin_bit_cast(uint16_t, h);
+                lo[u] = __builtin_bit_cast(uint16_t, (__bf16)(v - (float)h));
+            }
+            *reinterpret_cast<u16x8*>(ct + ch * 16) = hi;
+            *reinterpret_cast<u16x8*>(ct + KS * 1024 + ch * 16) = lo;
+        }
+        char* xt = reinterpret_cast<char*>(xf) + (long long)tile * XF_TILE;
+        for (int ch = tid; ch < 12 * 64; ch += 256) {        // chunk ((e*4 + fq)*16 + r): 8 slots of entry e, frame r
+            const int r = ch & 15, fq = (ch >> 4) & 3, e = ch >> 6;
+            u16x8 v;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sl = fq * 8 + u, j = sl / 6, term = sl - j * 6;
+                uint16_t parts[3] = {0, 0, 0};
+                if (j < NJ) split3_bf16(L.Gs[r][j * 12 + e], parts);
+                v[u] = j < NJ ? (XF_TERM_A[term] == 0 ? parts[0] : XF_TERM_A[term] == 1 ? parts[1] : parts[2]) : (uint16_t)0;
+            }
+            *reinterpret_cast<u16x8*>(xt + ch * 16) = v;
         }
     } else {
-        float* o = xf + (long long)f * (NJ * 12);
-        for (int i = lane; i < NJ * 12; i += 64) o[i] = G[i];
+        for (int i = tid; i < 16 * K; i += 256) {
+            const int r = i / K, k = i - r * K;
+            const long long ff = fbase + r;
+            if (r < nt) coef[((ff / FG) * K + k) * FG + (ff % FG)] = coefficient(r, k);
+        }
+        for (int i = tid; i < 16 * NJ * 12; i += 256) {
+            const int r = i / (NJ * 12), q = i - r * (NJ * 12);
+            if (r < nt) xf[(fbase + r) * (NJ * 12) + q] = L.Gs[r][q];
+        }
+    }
+}
+
+__device__ __forceinline__ void prep_shape_block(const AviFlameBasis& fb, const float* __restrict__ shape, int B, int cb,
+                                                 int gb, float* __restrict__ v_shaped, PrepShapeLds& L) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4, n = fb.V * 3;
+    const int ksteps = (fb.n_shape + 3) >> 2, per = (ksteps + 3) >> 2;
+    const int s0 = wave * per, s1 = s0 + per < ksteps ? s0 + per : ksteps;
+    const float* bp[2];
+    const float* sp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = cb * 32 + q * 16 + li, c = gb * 32 + q * 16 + li;
+        bp[q] = fb.shape_basis + (i < n ? i : n - 1);
+        sp[q] = shape + (long long)(c < B ? c : B - 1) * fb.n_shape;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q >> 1][q & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; s += 10) {     // ten k steps of loads in flight
+        float a[10][2], c[10][2];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int k = (s + u) * 4 + lk, kk = k < fb.n_shape ? k : fb.n_shape - 1;
+            const bool on = s + u < s1 && k < fb.n_shape;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[u][q] = on ? bp[q][(long long)kk * n] : 0.f;
+                c[u][q] = sp[q][kk];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[q >> 1][q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q >> 1], c[u][q & 1], acc[q >> 1][q & 1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) L.red[wave][q][lane] = acc[q >> 1][q & 1];
+    __syncthreads();
+    // wave w finishes tile (columns q >> 1, clips q & 1), q = w: lane holds clip li, columns 4 lk .. 4 lk + 3
+    const int q = wave, c = gb * 32 + (q & 1) * 16 + li, i = cb * 32 + (q >> 1) * 16 + lk * 4;
+    const f32x4 v = (L.red[0][q][lane] + L.red[1][q][lane]) + (L.red[2][q][lane] + L.red[3][q][lane]);
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = fb.v_template[i + r < n ? i + r : n - 1];
+    if (c < B) {
+        float* o = v_shaped + (long long)c * n + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i + r < n) o[r] = t[r] + v[r];
+    }
+}
+
+// grid: B * ceil(T/16) tile workgroups, then ceil(V*3/32) * ceil(B/32) shape workgroups
+__global__ __launch_bounds__(256) void flame_prep_kernel(const AviFlameBasis fb, const float* __restrict__ shape,
+                                                          const float* __restrict__ exp, const float* __restrict__ pose, int B,
+                                                          int T, float* __restrict__ v_shaped, float* __restrict__ coef,
+                                                          float* __restrict__ xf, int KP, int only) {
+    __shared__ PrepLds L;
+    const int ntile = (T + 15) >> 4, tiles = B * ntile;
+    if ((int)blockIdx.x < tiles) {
+        if (only == 2) return;      // diagnostic (AVI_FLAME_ONLY): time one kind of workgroup alone
+        const int b = blockIdx.x / ntile;
+        prep_tile_block(fb, shape, exp, pose, T, b, blockIdx.x - b * ntile, coef, xf, KP, L.t);
+    } else {
+        if (only == 1) return;
+        const int sb = blockIdx.x - tiles, ncb = (fb.V * 3 + 31) >> 5, gb = sb / ncb;
+        prep_shape_block(fb, shape, B, sb - gb * ncb, gb, v_shaped, L.s);
     }
 }
 
@@ -302,8 +367,6 @@ __global__ __launch_bounds__(512) void flame_vertices_kernel(const AviFlameBasis
 
 // ---- matrix-core path ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 48-byte runs of the output are dword aligned
 
 // basis planes [3][Vp][KP]: hi/lo[(c*Vp + v)*KP + k] = split of frame_basis[k][v*3 + c]; zero for v >= V, k >= K
 __global__ __launch_bounds__(256) void flame_pack_basis_kernel(const AviFlameBasis fb, int Vp, int KP,
@@ -409,6 +472,11 @@ __global__ __launch_bounds__(256, OCC) void flame_vertices_mfma_kernel(const Avi
         for (int c = 0; c < 3; ++c) vs[c][j] = v_shaped[(long long)b * n3 + vi * 3 + c];
     }
     const bool full = vt * 16 + 16 <= fb.V;            // wave-uniform
+    // a zero accumulator the compiler cannot fold: with a literal zero it picks the MFMA form whose result overwrites
+    // its accumulator operand and clears 4 registers before each of the 12 transform products (48 moves per tile)
+    f32x4 zero4;
+    asm("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+        : "=v"(zero4[0]), "=v"(zero4[1]), "=v"(zero4[2]), "=v"(zero4[3]));
     int buf = 0;
     for (int ti = 0; ti < ntile; ++ti, buf ^= 1) {
         const int f0 = fbeg + ti * 16;
@@ -440,7 +508,7 @@ __global__ __launch_bounds__(256, OCC) void flame_vertices_mfma_kernel(const Avi
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 t[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *reinterpret_cast<const bf16x8*>(xb + (r * 4 + e) * 1024),
-                                                               (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                                               zero4, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 o[j * 3 + r] = fmaf(t[2][j], acc[2][j], fmaf(t[1][j], acc[1][j], fmaf(t[0][j], acc[0][j], t[3][j])));
@@ -487,45 +555,41 @@ extern "C" int avi_flame_vertices(const AviFlameBasis* fbp, const float* shape, 
     if (!fbp || !shape || !exp || !pose || !v_shaped || !coef || !xf || !verts || B <= 0 || T <= 0) return AVI_EINVAL;
     const AviFlameBasis& fb = *fbp;
     if (!fb.v_template || !fb.shape_basis || !fb.frame_basis || !fb.j_template || !fb.j_shape || !fb.j_exp ||
-        !fb.lbs_weights || fb.V <= 0 || fb.n_shape <= 0 || fb.n_exp <= 0 || fb.n_exp > 124)
+        !fb.lbs_weights || fb.V <= 0 || fb.n_shape <= 0 || fb.n_exp <= 0 || fb.n_exp > MAX_EXP)
         return AVI_EINVAL;
     const int K = fb.n_exp + NPF;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int F = B * T, ntile = (T + 15) / 16;
-    const long long xf_floats = (long long)F * (NJ * 12) > (long long)B * ntile * (XF_TILE / 4) ? (long long)F * (NJ * 12)
-                                                                                                : (long long)B * ntile * (XF_TILE / 4);
-    float* jclip = xf + xf_floats;                  // [B][16] behind the transforms
-    hipLaunchKernelGGL(flame_shape_kernel, dim3((fb.V * 3 + 63) / 64 + 1, (B + SC - 1) / SC), dim3(256), 0, s, fb, shape, B,
-                       v_shaped, jclip);
-    if (fb.basis_hi && fb.basis_lo && K <= 160) {   // matrix-core path
-        if ((reinterpret_cast<uintptr_t>(fb.basis_hi) | reinterpret_cast<uintptr_t>(fb.basis_lo) |
-             reinterpret_cast<uintptr_t>(coef) | reinterpret_cast<uintptr_t>(xf)) & 15)
-            return AVI_EINVAL;
-        const int KS = K <= 96 ? 3 : 5, KP = KS * 32, Vp = (fb.V + 15) / 16 * 16;
-        hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, KP);
+    const int ntile = (T + 15) / 16;
+    const long long blocks = (long long)B * ntile + (long long)((fb.V * 3 + 31) / 32) * ((B + 31) / 32);
+    if (blocks > (1ll << 30)) return AVI_EINVAL;
+    const bool mc = fb.basis_hi && fb.basis_lo && K <= 160;
+    const int smem = K * 3 * VT * (int)sizeof(float);      // the vector-pipe kernel keeps the whole basis slice in LDS
+    if (!mc && smem > 160 * 1024) return AVI_EINVAL;
+    const int KSm = K <= 96 ? 3 : 5;
+    if (mc && ((reinterpret_cast<uintptr_t>(fb.basis_hi) | reinterpret_cast<uintptr_t>(fb.basis_lo) |
+                reinterpret_cast<uintptr_t>(coef) | reinterpret_cast<uintptr_t>(xf)) & 15))
+        return AVI_EINVAL;
+    static const int only = getenv("AVI_FLAME_ONLY") ? atoi(getenv("AVI_FLAME_ONLY")) : 0;
+    hipLaunchKernelGGL(flame_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fb, shape, exp, pose, B, T, v_shaped, coef,
+                       xf, mc ? KSm * 32 : 0, only);
+    if (mc) {   // matrix-core path
+        const int KS = KSm, Vp = (fb.V + 15) / 16 * 16;
         const int nx = (Vp / 16 + 3) / 4;
         const long long total = (long long)nx * B;
         if (total > (1ll << 30)) return AVI_EINVAL;
         const dim3 grid((unsigned)((total + 7) / 8 * 8));
         const char* ct = reinterpret_cast<const char*>(coef);
         const char* xt = reinterpret_cast<const char*>(xf);
-        static const int occ = getenv("AVI_FLAME_OCC") ? atoi(getenv("AVI_FLAME_OCC")) : 3;
-        if (KS == 3 && occ == 3)
+        if (KS == 3)
             hipLaunchKernelGGL((flame_vertices_mfma_kernel<3, 3>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
-                               (int)total, verts);
-        else if (KS == 3)
-            hipLaunchKernelGGL((flame_vertices_mfma_kernel<3, 2>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
                                (int)total, verts);
         else
             hipLaunchKernelGGL((flame_vertices_mfma_kernel<5, 2>), grid, dim3(256), 0, s, fb, v_shaped, ct, xt, T, Vp, nx,
                                (int)total, verts);
         return avi_launch_status();
     }
-    const int smem = K * 3 * VT * (int)sizeof(float);
-    if (smem > 160 * 1024) return AVI_EINVAL;
     static AviLdsGrant lds_grant;
     lds_grant.ensure(reinterpret_cast<const void*>(flame_vertices_kernel), 160 * 1024);
-    hipLaunchKernelGGL(flame_frame_kernel, dim3((F + 3) / 4), dim3(256), 0, s, fb, jclip, exp, pose, T, F, coef, xf, 0);
     hipLaunchKernelGGL(flame_vertices_kernel, dim3((fb.V + VT - 1) / VT, B), dim3(512), smem, s, fb, v_shaped, coef, xf,
                        T, verts);
     return avi_launch_status();

@@ -19,6 +19,11 @@
 //  12  as 10 (padded pitch, renumbered) with the buffer's base moved by 4 B: every run misaligned, pitch still 64-B
 //  13  as 10 with the base moved by 52 B per ... (pitch 60 288, run offset = (frame * 52) % 128 bytes: the real layout's
 //      phase walk without its pitch)
+//  20  as 5 (slab order, renumbered) with at most two tiles of stores in flight per wave (s_waitcnt vmcnt(3) per tile)
+//  21  as 20 at 3 workgroups per CU (50 KB of LDS each)
+//  22  as 21 with the kernel's operand traffic: 18 KB of LDS-DMA per workgroup and tile, one tile ahead, one barrier
+//  23  as 22 with 10 KB per tile
+//  24  as 22 at 2 workgroups per CU
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -48,6 +53,48 @@ __global__ __launch_bounds__(NT) void wide_kernel(float* __restrict__ verts, lon
                 if (nt) __builtin_nontemporal_store(val, reinterpret_cast<f32x4u*>(dst));
                 else *reinterpret_cast<f32x4u*>(dst) = val;
             }
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// DMA: KiB of operands per tile (0 = none); LDSKB: LDS held per workgroup; throttle as the product kernel
+template <int DMA, int LDSKB>
+__global__ __launch_bounds__(256) void loop_kernel(float* __restrict__ verts, long long pitch, const char* __restrict__ ops) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y, per = total / 8;
+    const int L = (id % 8) * per + id / 8;
+    const int by = L / gridDim.x, bx = L - by * gridDim.x;
+    const int vt = bx * 4 + wave;
+    const bool full = vt * 16 + 16 <= V;
+    const int fbeg = by * T, fend = fbeg + T;
+    const char* src = ops + (long long)by * 16 * DMA * 1024;
+    auto issue = [&](int ti, int buf) {
+        for (int c = wave; c < DMA; c += 4)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + ((long long)ti * DMA + c) * 1024 + lane * 16),
+                                             (lds_void*)(lds + (buf * DMA + c) * 1024), 16, 0, 0);
+    };
+    if (DMA) issue(0, 0);
+    int buf = 0, ti = 0;
+    for (int f0 = fbeg; f0 < fend; f0 += 16, ++ti, buf ^= 1) {
+        if (full && ti) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DMA) {
+            __syncthreads();
+            if (f0 + 16 < fend) issue(ti + 1, buf ^ 1);
+        }
+        if (!full) continue;
+        f32x4 val = {(float)f0, (float)lane, 1.f, 2.f};
+        if (DMA) val[2] = *reinterpret_cast<const float*>(lds + buf * DMA * 1024 + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int cidx = i * 64 + lane, fl = cidx / 12, piece = cidx - fl * 12;
+            const int ff = f0 + fl < fend ? f0 + fl : fend - 1;
+            float* dst = verts + (long long)ff * pitch + vt * 48 + piece * 4;
+            *reinterpret_cast<f32x4u*>(dst) = val;
         }
     }
 }
@@ -131,7 +178,11 @@ int main() {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     const dim3 grid((V / 16 + 3) / 4, B);
-    for (int mode = 0; mode < 14; ++mode) {
+    char* ops;
+    (void)hipMalloc(&ops, 32ll * 16 * 18 * 1024);
+    (void)hipMemset(ops, 0, 32ll * 16 * 18 * 1024);
+    for (int mode = 0; mode < 25; ++mode) {
+        if (mode > 13 && mode < 20) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             (void)hipEventRecord(e0, 0);
@@ -149,6 +200,11 @@ int main() {
                 case 11: hipLaunchKernelGGL(store_kernel<11>, grid, dim3(256), 0, 0, buf, (long long)V * 3); break;
                 case 12: hipLaunchKernelGGL(store_kernel<10>, grid, dim3(256), 0, 0, buf + 1, pitch_pad); break;
                 case 13: hipLaunchKernelGGL(store_kernel<13>, grid, dim3(256), 0, 0, buf, pitch_pad); break;
+                case 20: hipLaunchKernelGGL((loop_kernel<0, 0>), grid, dim3(256), 0, 0, buf, (long long)V * 3, ops); break;
+                case 21: hipLaunchKernelGGL((loop_kernel<0, 50>), grid, dim3(256), 50 * 1024, 0, buf, (long long)V * 3, ops); break;
+                case 22: hipLaunchKernelGGL((loop_kernel<18, 50>), grid, dim3(256), 50 * 1024, 0, buf, (long long)V * 3, ops); break;
+                case 23: hipLaunchKernelGGL((loop_kernel<10, 50>), grid, dim3(256), 50 * 1024, 0, buf, (long long)V * 3, ops); break;
+                case 24: hipLaunchKernelGGL((loop_kernel<18, 70>), grid, dim3(256), 70 * 1024, 0, buf, (long long)V * 3, ops); break;
                 case 4: hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<f32x4*>(buf), F * V * 3 / 4); break;
             }
             (void)hipEventRecord(e1, 0);
