@@ -1,0 +1,698 @@
+// FaceFormer autoregressive decode for WIDE decoders and SMALL batches as ONE persistent launch
+// (avi_faceformer_decode_persistent; models/faceformer.py:710-729 = `predict`'s loop, KV-cached as in faceformer_steps.hip).
+//
+// faceformer_steps.hip cuts a frame into 6 launches.  At B = 1 each of them lasts 5-10 us although it moves a few hundred
+// KB: a launch starts with cold L2s (the XCDs' L2s are written back / invalidated at kernel boundaries), so every launch
+// re-fetches its weight slice through the fabric, then waits for its inputs, then drains - 40 us per frame for 22 MB of
+// weights that never change.  Here the weights never move: 256 workgroups, one per CU (the launch needs all 256 CUs of an
+// MI355X free: 133 KB of LDS each), and workgroup g keeps ITS rows of every matrix in LDS for the whole decode, in fp32:
+//     fused q/k/v map  3D/256 columns x 64      out_proj | vertice_map  D/256 rows x (D + 64)
+//     linear1          2D/256 rows x D          linear2                 D/256 rows x 2D          vertice_map_r  1 row (g < 64)
+// (90 KB at D = 1024).  What moves between CUs is the frame's activation vectors, as data-tagged 8-byte granules
+// {value, tag} in device memory (one relaxed agent-scope store each, polled with relaxed agent-scope loads; the mechanism of
+// prior_pair.hip): tag = launch epoch << 16 | (6 frame + edge + 1), so a granule says by itself whether it is the one
+// awaited - no flags, no fences, no barrier.  Six edges per frame:
+//     o_{i-1} (64)  ->  A  every workgroup: its 3D/256 columns of q, k, v                                   -> QKV
+//     QKV           ->  B  16 workgroups (head h, key residue s = j mod 4): softmax partial (m, l, acc) over ITS keys of the
+//                          cache (it alone ever reads them: plain loads, its own L2), key i appended by residue i mod 4   -> PART
+//     PART          ->  C  every workgroup: merge of the 16 partials, its rows of s1 = x + out_proj(att)    -> S1
+//     S1            ->  D  every workgroup: x2 = LN2(LN1(s1) + cross_i) (whole rows, redundantly), its rows of relu(linear1) -> H
+//     H             ->  E  every workgroup: its rows of s3 = x2 + linear2(h)                                -> S3
+//     S3            ->  F  workgroups 0..63: LN3, one coefficient each (vertice_map_r), the frame's output   -> O
+// Every spin is bounded: a workgroup that never sees a granule (the launch did not get all its CUs, a foreign kernel holds
+// one) gives up ONCE, takes NaN from then on - so does everything downstream, with correct tags, nobody else stalls - and
+// raises AVI_STATUS_EXCHANGE_TIMEOUT; the launch always drains.  Arithmetic: fp32 multiply-adds on fp32 weights (the launch
+// chain's 3-term bf16 products agree to ~1e-6); LayerNorms two-pass.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256, NH = 4, VP = 64, PB = 2, NWG = 256, KSP = 4, NATT = NH * KSP, NEDGE = 6, KEYMAX = 256, PF = 16;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr int XCH_HDR = 8;                // header words (u64): [0] launch epoch
+enum { E_QKV = 0, E_PART = 1, E_S1 = 2, E_H = 3, E_S3 = 4, E_O = 5 };
+
+struct Geo {
+    int D, dh, nq, no, n1, n2;          // rows of each matrix a workgroup owns
+    int sq, so, s1, s2;                 // padded row strides (floats): + 32 so that two rows met by one wave sit 32 banks apart
+    int oq, oo, o1, o2, orr, img;       // offsets of the slices in the image, and its size (floats)
+    long long xq, xp, xs1, xh, xs3, xo, xpar;   // exchange offsets (granules) inside one parity, size of a parity
+    int ps;                             // granules of one partial: [0] m, [1] l, [4 + d] acc
+};
+__host__ __device__ inline Geo geo(int D) {
+    Geo g;
+    g.D = D, g.dh = D / NH;
+    g.nq = 3 * D / NWG, g.no = D / NWG, g.n1 = 2 * D / NWG, g.n2 = D / NWG;
+    g.sq = VP, g.so = D + VP + 32, g.s1 = D + 32, g.s2 = 2 * D + 32;
+    g.oq = 0;
+    g.oo = g.oq + g.nq * g.sq;
+    g.o1 = g.oo + g.no * g.so;
+    g.o2 = g.o1 + g.n1 * g.s1;
+    g.orr = g.o2 + g.n2 * g.s2;
+    g.img = g.orr + D;
+    g.ps = g.dh + 4;
+    g.xq = 0;
+    g.xp = g.xq + (long long)PB * 3 * D;
+    g.xs1 = g.xp + (long long)PB * NATT * g.ps;
+    g.xh = g.xs1 + (long long)PB * D;
+    g.xs3 = g.xh + (long long)PB * 2 * D;
+    g.xo = g.xs3 + (long long)PB * D;
+    g.xpar = g.xo + (long long)PB * VP;
+    return g;
+}
+inline int lds_floats(const Geo& g) {
+    return g.img + PB * 2 * g.D + PB * VP + 1024 + 3 * g.dh + KEYMAX + NT * 4;
+}
+
+struct Persist {
+    AviFaceformerWeights w;
+    AviFaceformerPlanes p;
+    const float* image;
+    const float* cross;
+    float* kv;
+    float* out;
+    uint16_t* out16;
+    unsigned long long* xch;
+    unsigned* status;
+    int B, T, D, chunk;
+    int fault;            // avi_debug_fault_inject: the last workgroup leaves at once
+};
+
+struct Ex {
+    unsigned* status;
+    int* wg_dead;       // LDS: some thread of this workgroup has given up
+    bool dead;          // this thread (or, from the next stage on, its workgroup) has given up once: NaN from now on, no more
+                        // spinning - a launch that lost a workgroup pays ONE bounded spin per workgroup, not one per stage
+};
+
+__device__ __forceinline__ void publish(unsigned long long* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long peek(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the value of granule *p once it carries `tag` (gr = what an earlier peek saw); bounded
+__device__ __forceinline__ float settle(const unsigned long long* p, unsigned long long gr, unsigned tag, Ex& x) {
+    unsigned spins = 0;
+    while (!x.dead && (unsigned)(gr >> 32) != tag) {
+        if (++spins > SPIN_LIMIT) {
+            if (x.status) __hip_atomic_store(x.status + AVI_STATUS_EXCHANGE_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *x.wg_dead = 1;
+            x.dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        gr = peek(p);
+    }
+    return x.dead ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)gr);
+}
+// ---- small reductions on DPP lanes (a ds_bpermute round trip costs ~100 cycles; these are 2-7 vector instructions) ----
+#define FFP_DPP(x, ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rm, 0xF, false))
+// sum over each aligned group of 4 lanes, in all 4
+__device__ __forceinline__ float quad_sum(float v) {
+    v += FFP_DPP(v, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+    v += FFP_DPP(v, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+    return v;
+}
+// sums over lanes 0..31 and 32..63 (wave-uniform)
+__device__ __forceinline__ void half_sums(float v, float& lo, float& hi) {
+    v = quad_sum(v);
+    v += FFP_DPP(v, 0x141, 0xF);     // row_half_mirror
+    v += FFP_DPP(v, 0x140, 0xF);     // row_mirror: every lane of a 16-lane row holds the row's sum
+    v += FFP_DPP(v, 0x142, 0xA);     // row_bcast15 into rows 1 and 3
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// N values per thread summed (or maximised) over the workgroup, one barrier; every thread gets the results.  `red` slots
+// [slot .. slot + N) of 4 words each must not be in use by a reduction less than one barrier old.
+template <int N, bool MAX>
+__device__ __forceinline__ void block_reduce(float (&v)[N], float (*red)[4], int slot) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const float w = MAX ? wave_max_u(v[q]) : wave_sum_u(v[q]);
+        if ((threadIdx.x & 63) == 0) red[slot + q][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        v[q] = MAX ? fmaxf(fmaxf(red[slot + q][0], red[slot + q][1]), fmaxf(red[slot + q][2], red[slot + q][3]))
+                   : (red[slot + q][0] + red[slot + q][1]) + (red[slot + q][2] + red[slot + q][3]);
+}
+
+// element u * NT + tid of row b of a published vector (n <= E * NT values per row, row stride `stride` granules) -> v[b][u]
+template <int BT, int E>
+__device__ __forceinline__ void poll_regs(const unsigned long long* src, long long stride, int n, unsigned tag, Ex& x,
+                                          float (&v)[BT][E]) {
+    unsigned long long gr[BT][E];
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int k = u * NT + threadIdx.x;
+            gr[b][u] = (k < n && !x.dead) ? peek(src + b * stride + k) : 0ull;
+        }
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const int k = u * NT + threadIdx.x;
+            v[b][u] = k < n ? settle(src + b * stride + k, gr[b][u], tag, x) : 0.f;
+        }
+}
+
+// res[b * 16 + r] = sum_k W[r * ws + k] x[b * xs + k] for r < R = 1 << rs (R <= 8) and b < BT; K % 4 == 0; every thread takes
+// part; ends with a barrier.  NT / R consecutive lanes share a row and read it as float4: conflict-free LDS reads of W,
+// broadcast reads of x.  `red` slots [slot, slot + BT) are used when a row spans whole waves.
+template <int BT>
+__device__ __forceinline__ void gemv(const float* __restrict__ W, int ws, int rs, int K, const float* __restrict__ x, int xs,
+                                     float (*red)[4], int slot, float* __restrict__ res) {
+    const int tid = threadIdx.x, lsh = 8 - rs, lpr = 1 << lsh, r = tid >> lsh, l = tid & (lpr - 1), K4 = K >> 2;
+    float a[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) a[b] = 0.f;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(W + r * ws);
+#pragma unroll 4
+    for (int k = l; k < K4; k += lpr) {
+        const f32x4 wv = wr[k];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x + b * xs)[k];
+            a[b] = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], a[b]))));
+        }
+    }
+    if (lsh >= 6) {                          // a row is 1, 2 or 4 whole waves
+        const int wsh = lsh - 6;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const float w = wave_sum_u(a[b]);
+            if ((tid & 63) == 0) red[slot + b][tid >> 6] = w;
+        }
+        __syncthreads();
+        if (tid < (BT << rs)) {
+            const int rr = tid & ((1 << rs) - 1), b = tid >> rs;
+            float sum = 0.f;
+            for (int q = 0; q < (1 << wsh); ++q) sum += red[slot + b][(rr << wsh) + q];
+            res[b * 16 + rr] = sum;
+        }
+    } else {                                 // lpr == 32: two rows per wave
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            float lo, hi;
+            half_sums(a[b], lo, hi);
+            if ((tid & 63) == 0) {
+                res[b * 16 + r] = lo;
+                res[b * 16 + r + 1] = hi;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// AVI_FFP_STAMPS (diagnostic build, scripts/ffp_stamps.py): thread 0 of workgroups 0 and 200 adds up the time (100 MHz ticks)
+// between the marks below over all frames; at the end the sums overwrite the first floats of the output.
+#ifdef AVI_FFP_STAMPS
+#define FFP_STAMP(k)                                         \
+    do {                                                     \
+        if (tid == 0) {                                      \
+            const long long t_ = wall_clock64();             \
+            stamp_acc[k] += t_ - stamp_last;                 \
+            stamp_last = t_;                                 \
+        }                                                    \
+    } while (0)
+#else
+#define FFP_STAMP(k) do { } while (0)
+#endif
+
+template <int BT>
+__global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Geo G = geo(c.D);
+    constexpr int E = 4;                    // values of a D-long row per thread (D <= 1024)
+    const int D = c.D, dh = G.dh, tid = threadIdx.x, g = blockIdx.x;
+    const int dsh = 31 - __builtin_clz(dh);                 // dh is a power of two
+    float* img = lds;
+    float* vec = img + G.img;               // [PB][2D]: the frame's activation rows, one stage after the other
+    float* ov = vec + PB * 2 * D;           // [PB][VP]: the previous coefficient frame (normalised)
+    float (*red)[4] = reinterpret_cast<float (*)[4]>(ov + PB * VP);   // [32][4] reduction slots
+    float* res = ov + PB * VP + 128;        // [PB][16]
+    float* ml = res + PB * 16;              // [PB][NATT][2]
+    int* wg_dead = reinterpret_cast<int*>(ml + PB * NATT * 2);
+    float* qs = ov + PB * VP + 1024;        // [dh]
+    float* ks = qs + dh;
+    float* vs = ks + dh;
+    float* sc = vs + dh;                    // [KEYMAX]
+    float* accr = sc + KEYMAX;              // [NT * 4]
+    if (c.fault && g == NWG - 1) return;
+    for (int i = tid; i < G.img / 4; i += NT)
+        reinterpret_cast<f32x4*>(img)[i] = reinterpret_cast<const f32x4*>(c.image + (long long)g * G.img)[i];
+    Ex x;
+    x.status = c.status;
+    x.wg_dead = wg_dead;
+    x.dead = false;
+    if (tid == 0) *wg_dead = 0;
+    const unsigned epoch = (unsigned)(peek(c.xch) & 0xFFFFu);
+    unsigned long long* xbase = c.xch + XCH_HDR;
+    const float scale = rsqrtf((float)dh);
+    // per-thread constants: LayerNorm gains / biases of my E columns, biases of my rows
+    float g1[E], b1n[E], g2[E], b2n[E], g3[E], b3n[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int d = u * NT + tid, dd = d < D ? d : 0;
+        g1[u] = c.w.n1g[dd], b1n[u] = c.w.n1b[dd], g2[u] = c.w.n2g[dd], b2n[u] = c.w.n2b[dd];
+        g3[u] = c.w.n3g[dd], b3n[u] = c.w.n3b[dd];
+    }
+    const int ro = tid & (G.no - 1), r1 = tid & (G.n1 - 1), r2 = tid & (G.n2 - 1);    // my row when tid < BT * rows
+    const float bias_o = c.w.bo[g * G.no + ro], bias_m = c.w.bm[g * G.no + ro], bias_1 = c.w.b1[g * G.n1 + r1];
+    const float bias_2 = c.w.b2[g * G.n2 + r2], bias_r = g < c.w.V ? c.w.br[g] : 0.f;
+    const int rso = 31 - __builtin_clz(G.no), rs1 = 31 - __builtin_clz(G.n1), rs2 = 31 - __builtin_clz(G.n2);
+    __syncthreads();
+#ifdef AVI_FFP_STAMPS
+    long long stamp_acc[16] = {0}, stamp_last = wall_clock64();
+#endif
+
+    for (int i = 0; i < c.T; ++i) {
+        const int phase = i % c.w.period;
+        if (*reinterpret_cast<volatile int*>(wg_dead)) x.dead = true;
+        unsigned long long* X = xbase + (long long)(i & 1) * G.xpar;
+        const unsigned tb = (epoch << 16) | (unsigned)(i * NEDGE + 1);      // tag of edge e of this frame: tb + e
+        // loads of this frame that depend on nothing: requested before the first wait
+        float crs[BT][E];                   // cross_i, my E columns
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+#pragma unroll
+            for (int u = 0; u < E; ++u) {
+                const int d = u * NT + tid;
+                crs[b][u] = d < D ? c.cross[((long long)b * c.T + i) * D + d] : 0.f;
+            }
+        const float pe_o = i == 0 ? c.p.x0[g * G.no + ro] : bias_m + c.w.pe[(long long)phase * D + g * G.no + ro];
+
+        // ---- A: my columns of q, k, v from the previous coefficient frame ----------------------------------------------
+        const int oi = tid >> 2, part = tid & 3, bq = oi / G.nq, rq = oi - bq * G.nq;      // output (row bq, column rq), quarter
+        const bool qon = oi < BT * G.nq;
+        const float bfq = i == 0 ? (qon ? c.p.qkv0[g * G.nq + rq] : 0.f)
+                                 : (qon ? c.p.bf[(long long)phase * 3 * D + g * G.nq + rq] : 0.f);
+        if (i > 0 && tid < BT * VP) {
+            const unsigned long long* p = xbase + (long long)((i - 1) & 1) * G.xpar + G.xo + tid;
+            ov[tid] = settle(p, x.dead ? 0ull : peek(p), tb - NEDGE + E_O, x);
+        }
+        __syncthreads();
+        FFP_STAMP(0);       // waited for o_{i-1}
+        {
+            float a = 0.f;
+            if (i > 0 && qon) {
+                const float* wq = img + G.oq + rq * G.sq + part * 16;
+                const float* o = ov + bq * VP + part * 16;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) a = fmaf(wq[v], o[v], a);
+            }
+            a = quad_sum(a);
+            if (qon && part == 0) publish(X + G.xq + (long long)bq * 3 * D + g * G.nq + rq, bfq + a, tb + E_QKV);
+        }
+        FFP_STAMP(1);       // q/k/v columns
+
+        // ---- B: split-key attention partials (16 workgroups) -----------------------------------------------------------
+        if (g < NATT) {
+            const int h = g / KSP, s = g - h * KSP, hoff = h * dh;
+            const int kstart = (i / c.chunk) * c.chunk;
+            const int j0 = kstart + ((s - kstart % KSP) + KSP) % KSP;     // my first key of the window; keys j0, j0 + 4, ...
+            const int nk = i >= j0 ? (i - j0) / KSP + 1 : 0;
+            const bool owner = (i % KSP) == s;                            // then my LAST key is frame i itself
+            const int LPK = dh >> 2, lpsh = dsh - 2, groups = NT >> lpsh, gk = tid >> lpsh, l = tid & (LPK - 1);
+            const int nd4 = dh >> 4;                                      // float4s of a key a score thread covers (<= 16)
+            const float slope = c.w.slopes[h];
+            for (int b = 0; b < BT; ++b) {
+                float* kvb = c.kv + (long long)b * c.T * 2 * D;
+                // my rows of the cache do not depend on q: requested before the poll.  Scores: thread (key tid / 4, quarter
+                // tid % 4 of the head dimension); P.V: thread (key group gk, float4 column l).
+                f32x4 kpre[16], vpre[PF];
+                const int n0 = tid >> 2;
+                {
+                    const int j = j0 + n0 * KSP;
+                    const bool on = n0 < nk && j != i;
+                    const f32x4* kr = reinterpret_cast<const f32x4*>(kvb + (long long)(on ? j : 0) * 2 * D + hoff) + part * nd4;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) kpre[q] = (on && q < nd4) ? kr[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int n = gk + u * groups, j = j0 + n * KSP;
+                    vpre[u] = (n < nk && j != i) ? *reinterpret_cast<const f32x4*>(kvb + (long long)j * 2 * D + D + hoff + 4 * l)
+                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                {
+                    const unsigned long long* Xq = X + G.xq + (long long)b * 3 * D + hoff;
+                    const int nw = owner ? 3 : 1;
+                    unsigned long long gr[3];
+#pragma unroll
+                    for (int w3 = 0; w3 < 3; ++w3) gr[w3] = (w3 < nw && tid < dh && !x.dead) ? peek(Xq + w3 * D + tid) : 0ull;
+#pragma unroll
+                    for (int w3 = 0; w3 < 3; ++w3)
+                        if (w3 < nw && tid < dh) {
+                            const float v = settle(Xq + w3 * D + tid, gr[w3], tb + E_QKV, x);
+                            (w3 == 0 ? qs : w3 == 1 ? ks : vs)[tid] = v;
+                            if (w3 > 0) kvb[(long long)i * 2 * D + (w3 - 1) * D + hoff + tid] = v;
+                        }
+                }
+                __syncthreads();
+                // scores of keys n = 64 p + tid / 4; pass 0 from the prefetched rows
+                float sco[KEYMAX / 64], mx[1] = {-3.0e38f};
+#pragma unroll
+                for (int p = 0; p < KEYMAX / 64; ++p) {
+                    sco[p] = -3.0e38f;
+                    if (p * 64 >= nk) continue;                            // workgroup-uniform
+                    const int n = p * 64 + n0, j = j0 + n * KSP;
+                    const bool on = n < nk;
+                    const f32x4* q4 = reinterpret_cast<const f32x4*>(qs) + part * nd4;
+                    const f32x4* kl = reinterpret_cast<const f32x4*>(ks) + part * nd4;
+                    const f32x4* kg = reinterpret_cast<const f32x4*>(kvb + (long long)(on ? j : 0) * 2 * D + hoff) + part * nd4;
+                    float d = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (q < nd4) {
+                            const f32x4 k4 = (on && j == i) ? kl[q] : (p == 0 ? kpre[q] : (on ? kg[q] : (f32x4){0.f, 0.f, 0.f, 0.f}));
+                            const f32x4 qq = q4[q];
+                            d = fmaf(qq[0], k4[0], fmaf(qq[1], k4[1], fmaf(qq[2], k4[2], fmaf(qq[3], k4[3], d))));
+                        }
+                    }
+                    d = quad_sum(d);
+                    if (on) {
+                        sco[p] = d * scale - slope * (float)((i - j) / c.w.period);
+                        mx[0] = fmaxf(mx[0], sco[p]);
+                    }
+                }
+                block_reduce<1, true>(mx, red, 0);
+                float sum[1] = {0.f};
+#pragma unroll
+                for (int p = 0; p < KEYMAX / 64; ++p) {
+                    const int n = p * 64 + n0;
+                    if (n < nk && part == 0) {
+                        const float pj = __expf(sco[p] - mx[0]);
+                        sc[n] = pj;
+                        sum[0] += pj;
+                    }
+                }
+                block_reduce<1, false>(sum, red, 1);    // its barrier also publishes sc[] to every thread
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int n = gk + u * groups;
+                    if (n < nk) a += sc[n] * (j0 + n * KSP == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l) : vpre[u]);
+                }
+                for (int n = gk + PF * groups; n < nk; n += groups) {
+                    const int j = j0 + n * KSP;
+                    a += sc[n] * (j == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l)
+                                         : *reinterpret_cast<const f32x4*>(kvb + (long long)j * 2 * D + D + hoff + 4 * l));
+                }
+                *reinterpret_cast<f32x4*>(accr + 4 * tid) = a;
+                __syncthreads();
+                unsigned long long* Xp = X + G.xp + (long long)(b * NATT + g) * G.ps;
+                if (tid < dh) {
+                    const int lq = tid >> 2, comp = tid & 3;
+                    float r = 0.f;
+                    for (int gg = 0; gg < groups; ++gg) r += accr[4 * (gg * LPK + lq) + comp];
+                    publish(Xp + 4 + tid, r, tb + E_PART);
+                }
+                if (tid == 0) {
+                    publish(Xp + 0, nk > 0 ? mx[0] : -3.0e38f, tb + E_PART);
+                    publish(Xp + 1, nk > 0 ? sum[0] : 0.f, tb + E_PART);
+                }
+                __syncthreads();                       // qs / ks / vs / sc / accr are free for the next row
+            }
+        }
+        FFP_STAMP(2);       // attention (workgroups 0..15)
+
+        // ---- C: merged attention, my rows of s1 = x + out_proj(att) ---------------------------------------------------
+        if (tid < BT * NATT * 2) {
+            const int bb = tid / (NATT * 2), r = tid - bb * NATT * 2;
+            const unsigned long long* p = X + G.xp + (long long)(bb * NATT + (r >> 1)) * G.ps + (r & 1);
+            ml[tid] = settle(p, x.dead ? 0ull : peek(p), tb + E_PART, x);
+        }
+        {
+            // the accumulators of my E columns: requested before the (m, l) pairs are waited for
+            unsigned long long gr[BT][E][KSP];
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+#pragma unroll
+                for (int u = 0; u < E; ++u) {
+                    const int d = u * NT + tid, h = d >> dsh, dd = d & (dh - 1);
+#pragma unroll
+                    for (int s = 0; s < KSP; ++s)
+                        gr[b][u][s] = (d < D && !x.dead) ? peek(X + G.xp + (long long)(b * NATT + h * KSP + s) * G.ps + 4 + dd) : 0ull;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+#pragma unroll
+                for (int u = 0; u < E; ++u) {
+                    const int d = u * NT + tid, h = d >> dsh, dd = d & (dh - 1);
+                    if (d < D) {
+                        const float* mlh = ml + (b * NATT + h * KSP) * 2;
+                        float M = -3.0e38f;
+#pragma unroll
+                        for (int s = 0; s < KSP; ++s) M = fmaxf(M, mlh[2 * s]);
+                        float L = 0.f, r = 0.f;
+#pragma unroll
+                        for (int s = 0; s < KSP; ++s) {
+                            const float wgt = __expf(mlh[2 * s] - M);
+                            L = fmaf(wgt, mlh[2 * s + 1], L);
+                            r = fmaf(wgt, settle(X + G.xp + (long long)(b * NATT + h * KSP + s) * G.ps + 4 + dd, gr[b][u][s],
+                                                 tb + E_PART, x), r);
+                        }
+                        vec[b * 2 * D + d] = r / L;
+                    }
+                }
+        }
+        if (tid < BT * VP) vec[(tid / VP) * 2 * D + D + (tid % VP)] = i > 0 ? ov[tid] : 0.f;     // [att | o_{i-1}]
+        __syncthreads();
+        FFP_STAMP(3);       // waited for the partials, merged them
+        gemv<BT>(img + G.oo, G.so, rso, D + VP, vec, 2 * D, red, 2, res);
+        if (tid < BT * G.no) {
+            // x = vertice_map(o_{i-1}) + pe_i (frame 0: obj_embedding + pe_0); the vertice_map product came out of the same rows
+            const int bb = tid >> rso;
+            publish(X + G.xs1 + (long long)bb * D + g * G.no + ro, res[bb * 16 + ro] + bias_o + pe_o, tb + E_S1);
+        }
+        FFP_STAMP(4);       // out-projection rows
+
+        // ---- D: x2 = LN2(LN1(s1) + cross_i), my rows of h = relu(linear1 x2) ---------------------------------------------
+        {
+            float t[BT][E];
+            poll_regs<BT, E>(X + G.xs1, D, D, tb + E_S1, x, t);
+            FFP_STAMP(5);   // waited for s1
+            const float invD = 1.f / D;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {          // LayerNorm 1 (+ cross), LayerNorm 2; two-pass statistics
+                float sm[BT], sq[BT];
+#pragma unroll
+                for (int b = 0; b < BT; ++b) {
+                    sm[b] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < E; ++u) sm[b] += t[b][u];           // columns past D hold 0
+                }
+                block_reduce<BT, false>(sm, red, 4 + pass * 2 * PB);
+#pragma unroll
+                for (int b = 0; b < BT; ++b) {
+                    sq[b] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < E; ++u)
+                        if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
+                }
+                block_reduce<BT, false>(sq, red, 4 + pass * 2 * PB + PB);
+#pragma unroll
+                for (int b = 0; b < BT; ++b) {
+                    const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
+#pragma unroll
+                    for (int u = 0; u < E; ++u)
+                        if (u * NT + tid < D)
+                            t[b][u] = pass == 0 ? (t[b][u] - mu) * rs * g1[u] + b1n[u] + crs[b][u] : (t[b][u] - mu) * rs * g2[u] + b2n[u];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+#pragma unroll
+                for (int u = 0; u < E; ++u)
+                    if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = t[b][u];
+            __syncthreads();
+        }
+        FFP_STAMP(6);       // two LayerNorms
+        const float x2own = tid < BT * G.n2 ? vec[(tid >> rs2) * 2 * D + g * G.n2 + r2] : 0.f;   // linear2's residual, my rows
+        gemv<BT>(img + G.o1, G.s1, rs1, D, vec, 2 * D, red, 2, res);
+        if (tid < BT * G.n1) {
+            const int bb = tid >> rs1;
+            publish(X + G.xh + (long long)bb * 2 * D + g * G.n1 + r1, fmaxf(res[bb * 16 + r1] + bias_1, 0.f), tb + E_H);
+        }
+        FFP_STAMP(7);       // linear1 rows
+
+        // ---- E: my rows of s3 = x2 + linear2 h ----------------------------------------------------------------------------
+        {
+            float t[BT][2 * E];
+            poll_regs<BT, 2 * E>(X + G.xh, 2 * D, 2 * D, tb + E_H, x, t);
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+#pragma unroll
+                for (int u = 0; u < 2 * E; ++u)
+                    if (u * NT + tid < 2 * D) vec[b * 2 * D + u * NT + tid] = t[b][u];
+            __syncthreads();
+        }
+        FFP_STAMP(8);       // waited for h
+        gemv<BT>(img + G.o2, G.s2, rs2, 2 * D, vec, 2 * D, red, 2, res);
+        if (tid < BT * G.n2) {
+            const int bb = tid >> rs2;
+            publish(X + G.xs3 + (long long)bb * D + g * G.n2 + r2, x2own + bias_2 + res[bb * 16 + r2], tb + E_S3);
+        }
+        FFP_STAMP(9);       // linear2 rows
+
+        // ---- F: coefficient g of the frame (workgroups 0..63) ----------------------------------------------------------
+        if (g < VP) {
+            float t[BT][E];
+            poll_regs<BT, E>(X + G.xs3, D, D, tb + E_S3, x, t);
+            FFP_STAMP(10);  // waited for s3
+            const float invD = 1.f / D;
+            float sm[BT], sq[BT];
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                sm[b] = 0.f;
+#pragma unroll
+                for (int u = 0; u < E; ++u) sm[b] += t[b][u];
+            }
+            block_reduce<BT, false>(sm, red, 4 + 4 * PB);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                sq[b] = 0.f;
+#pragma unroll
+                for (int u = 0; u < E; ++u)
+                    if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
+            }
+            block_reduce<BT, false>(sq, red, 4 + 5 * PB);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < E; ++u)
+                    if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = (t[b][u] - mu) * rs * g3[u] + b3n[u];
+            }
+            __syncthreads();
+            FFP_STAMP(11);  // LayerNorm 3
+            gemv<BT>(img + G.orr, D, 0, D, vec, 2 * D, red, 2, res);
+            if (tid < BT) {
+                const bool real = g < c.w.V;
+                float v = real ? res[tid * 16] + bias_r : 0.f;
+                publish(X + G.xo + (long long)tid * VP + g, v, tb + E_O);      // normalised: what vertice_map feeds back (:722-725)
+                if (real) {
+                    if (c.w.coeff_std) v = v * c.w.coeff_std[g] + c.w.coeff_mean[g];       // :729
+                    const long long oi2 = ((long long)tid * c.T + i) * c.w.V + g;
+                    if (c.out16) c.out16[oi2] = __builtin_bit_cast(uint16_t, (_Float16)v);
+                    else c.out[oi2] = v;
+                }
+            }
+            FFP_STAMP(12);  // vertice_map_r row, frame out
+        }
+    }
+#ifdef AVI_FFP_STAMPS
+    __syncthreads();
+    if (tid == 0 && (g == 0 || g == 200) && c.out)
+        for (int k = 0; k < 16; ++k) c.out[(g == 0 ? 0 : 16) + k] = (float)stamp_acc[k];
+#endif
+}
+
+// after the decode, in stream order: the next launch's epoch; every 2^16 launches the tag space wraps, so the slots are cleared
+__global__ void ff_persist_epoch_kernel(unsigned long long* __restrict__ ws, long long slot_words) {
+    __shared__ int wrap;
+    if (threadIdx.x == 0) {
+        const unsigned long long e = ws[0] + 1;
+        ws[0] = e;
+        wrap = (e & 0xFFFFull) == 0;
+    }
+    __syncthreads();
+    if (wrap)
+        for (long long i = threadIdx.x; i < slot_words; i += blockDim.x) ws[XCH_HDR + i] = 0ull;
+}
+
+// image[g] = workgroup g's rows of every matrix, fp32, padded strides (see Geo); grid NWG
+__global__ __launch_bounds__(NT) void ff_persist_pack_kernel(const AviFaceformerWeights w, const AviFaceformerPlanes p,
+                                                              float* __restrict__ image) {
+    const Geo G = geo(w.D);
+    const int D = w.D, g = blockIdx.x;
+    float* im = image + (long long)g * G.img;
+    for (int i = threadIdx.x; i < G.img; i += NT) {
+        float v = 0.f;
+        if (i < G.oo) {                       // fused q/k/v map: [nq][64], column g nq + r of wf_t [64][3D]
+            const int r = i / G.sq, k = i - r * G.sq;
+            v = p.wf_t[(long long)k * 3 * D + g * G.nq + r];
+        } else if (i < G.o1) {                // [out_proj | vertice_map] row n: wo [K = D][N = D], wm [V][D]
+            const int q = i - G.oo, r = q / G.so, k = q - r * G.so, n = g * G.no + r;
+            if (k < D) v = w.wo[(long long)k * D + n];
+            else if (k - D < w.V) v = w.wm[(long long)(k - D) * D + n];
+        } else if (i < G.o2) {                // linear1 row m: w1 [D][2D]
+            const int q = i - G.o1, r = q / G.s1, k = q - r * G.s1;
+            if (k < D) v = w.w1[(long long)k * 2 * D + g * G.n1 + r];
+        } else if (i < G.orr) {               // linear2 row n: w2 [2D][D]
+            const int q = i - G.o2, r = q / G.s2, k = q - r * G.s2;
+            if (k < 2 * D) v = w.w2[(long long)k * D + g * G.n2 + r];
+        } else {                              // vertice_map_r row g: wr [D][V]
+            const int k = i - G.orr;
+            if (g < w.V) v = w.wr[(long long)k * w.V + g];
+        }
+        im[i] = v;
+    }
+}
+
+bool persist_shape_ok(int D) { return D == 256 || D == 512 || D == 1024; }
+
+}  // namespace
+
+// *image_floats: size of the per-model LDS image (avi_faceformer_persist_pack); *xch_bytes: the exchange workspace, zero-filled
+// ONCE by the caller and then left to the library (it carries the launch epoch); one launch at a time may use it.
+extern "C" int avi_faceformer_persist_sizes(int D, long long* image_floats, long long* xch_bytes) {
+    if (!persist_shape_ok(D) || !image_floats || !xch_bytes) return AVI_EINVAL;
+    const Geo G = geo(D);
+    *image_floats = (long long)NWG * G.img;
+    *xch_bytes = 8 * (XCH_HDR + 2 * G.xpar);
+    return AVI_OK;
+}
+
+extern "C" int avi_faceformer_persist_pack(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, float* image,
+                                           void* stream) {
+    if (!w || !p || !image || !persist_shape_ok(w->D) || w->V < 1 || w->V > VP) return AVI_EINVAL;
+    if (!w->wo || !w->w1 || !w->w2 || !w->wr || !w->wm || !p->wf_t) return AVI_EINVAL;
+    if (reinterpret_cast<uintptr_t>(image) & 15) return AVI_EINVAL;
+    hipLaunchKernelGGL(ff_persist_pack_kernel, dim3(NWG), dim3(NT), 0, static_cast<hipStream_t>(stream), *w, *p, image);
+    return avi_launch_status();
+}
+
+extern "C" int avi_faceformer_decode_persistent(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* image,
+                                                const float* cross, int B, int T, int chunk, float* kv_scratch, void* xch,
+                                                float* out, uint16_t* out16, void* stream) {
+    if (!w || !p || !image || !cross || !kv_scratch || !xch || (!out && !out16) || B <= 0 || B > PB || T <= 0) return AVI_EINVAL;
+    if (!persist_shape_ok(w->D) || w->V < 1 || w->V > VP || w->period < 1) return AVI_EINVAL;
+    if ((long long)T * NEDGE + NEDGE >= 65535) return AVI_EINVAL;          // 16 bits of tag per launch
+    if (chunk <= 0 || chunk > T) chunk = T;
+    if (chunk < T && chunk % w->period) return AVI_EINVAL;
+    if (chunk > KEYMAX * KSP) return AVI_EINVAL;                            // a key residue's scores live in LDS
+    if (!p->bf || !p->qkv0 || !p->x0 || !w->bo || !w->b1 || !w->b2 || !w->br || !w->bm || !w->pe || !w->slopes || !w->n1g ||
+        !w->n1b || !w->n2g || !w->n2b || !w->n3g || !w->n3b)
+        return AVI_EINVAL;
+    if ((w->coeff_mean == nullptr) != (w->coeff_std == nullptr)) return AVI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xch) & 7) || (reinterpret_cast<uintptr_t>(image) & 15)) return AVI_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < NWG)
+        return AVI_EINVAL;                                                  // one workgroup per CU, all resident at once
+    const Geo G = geo(w->D);
+    const int smem = lds_floats(G) * (int)sizeof(float);
+    static AviLdsGrant grant1, grant2;
+    grant1.ensure(reinterpret_cast<const void*>(ff_persist_kernel<1>), 160 * 1024);
+    grant2.ensure(reinterpret_cast<const void*>(ff_persist_kernel<2>), 160 * 1024);
+    if (smem > 160 * 1024) return AVI_EINVAL;
+    Persist c;
+    c.w = *w, c.p = *p, c.image = image, c.cross = cross, c.kv = kv_scratch, c.out = out, c.out16 = out16;
+    c.xch = static_cast<unsigned long long*>(xch);
+    c.status = avi_status_ptr();
+    c.B = B, c.T = T, c.D = w->D, c.chunk = chunk;
+    c.fault = avi_fault_injected() & AVI_FAULT_EXCHANGE_ABSENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (B == 1) hipLaunchKernelGGL(ff_persist_kernel<1>, dim3(NWG), dim3(NT), smem, s, c);
+    else hipLaunchKernelGGL(ff_persist_kernel<2>, dim3(NWG), dim3(NT), smem, s, c);
+    hipLaunchKernelGGL(ff_persist_epoch_kernel, dim3(1), dim3(256), 0, s, c.xch, 2 * G.xpar);
+    return avi_launch_status();
+}

@@ -79,9 +79,33 @@ __global__ __launch_bounds__(NT) void ff_attn_kernel(const Chain c, const int i,
         }
     }
     if (i > 0 && tid < VP) ov[tid] = c.o[b * VP + tid];
-    __syncthreads();
-    // q (every split), k and v (the owning split): 64-long dot products against the fused matrix, coalesced over outputs
-    for (int idx = tid; idx < (owns_i ? 3 : 1) * dh; idx += NT) {
+    // q (every split), k and v (the owning split): 64-long dot products against the fused matrix, coalesced over outputs.
+    // The matrix columns of a thread's FIRST output do not depend on the previous frame: they are requested before the
+    // barrier that publishes it (one memory round trip less on the frame's critical path: 10.1 -> 9.2 us per launch).
+    const int nq = (owns_i ? 3 : 1) * dh;
+    {
+        const int idx0 = tid < nq ? tid : nq - 1;
+        const int which0 = idx0 / dh, d0 = idx0 - which0 * dh, col0 = which0 * D + h * dh + d0;
+        float a0, wv0[VP];
+        if (i == 0) {
+            a0 = c.p.qkv0[col0];
+        } else {
+            a0 = c.p.bf[(long long)(i % c.w.period) * 3 * D + col0];
+            const float* wcol = c.p.wf_t + col0;
+#pragma unroll
+            for (int v = 0; v < VP; ++v) wv0[v] = wcol[(long long)v * 3 * D];
+        }
+        __syncthreads();
+        if (i > 0) {
+#pragma unroll
+            for (int v = 0; v < VP; ++v) a0 = fmaf(wv0[v], ov[v], a0);
+        }
+        if (tid < nq) {
+            (which0 == 0 ? qs : which0 == 1 ? ks : vs)[d0] = a0;
+            if (which0 > 0) kvb[(long long)i * 2 * D + (which0 - 1) * D + h * dh + d0] = a0;
+        }
+    }
+    for (int idx = tid + NT; idx < nq; idx += NT) {
         const int which = idx / dh, d = idx - which * dh, col = which * D + h * dh + d;
         float a;
         if (i == 0) {

@@ -13,12 +13,16 @@ decodes B utterances at once with a KV cache.  Two device paths behind ``decode`
   * narrow decoders (D < 256): all T steps in ONE launch, one workgroup per utterance (csrc/faceformer.hip);
   * wide decoders (D >= 256, e.g. feature_dim 1024 of config/vocaset/demo.yaml): a chain of 6-7 small launches per
     frame, each spread over the whole chip (csrc/faceformer_steps.hip), captured once per (B, T, chunk) in a hipGraph
-    and replayed.
+    and replayed;
+  * wide decoders, ONE utterance (two on request) (D in 256 / 512 / 1024): ONE persistent launch of 256 workgroups that keep their
+    rows of every matrix in LDS and exchange the frame's vectors as tagged granules (csrc/faceformer_persist.hip); the
+    launch chain is its fallback (``decode_checked``) and the path for larger batches.
 Long-form (T > 600, which the reference's tables do not reach: models/faceformer.py:88,147): ``decode(..., chunk=C)``
 selects the chunked-causal window defined in include/avi_talking.h (avi_faceformer_decode_chunked).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -112,13 +116,21 @@ class Faceformer:
             cw.coeff_mean = dev(torch.as_tensor(coeff_mean, dtype=torch.float32).reshape(-1)[: self.V])
             cw.coeff_std = dev(torch.as_tensor(coeff_std, dtype=torch.float32).reshape(-1)[: self.V])
         self.cw = cw
-        import os
         mode = os.environ.get("AVI_FF_STEPS", "auto")           # "0" / "1" force a path (tests), auto: by width
         dh = D // NHEAD
         can = D % 64 == 0 and D <= 1024 and dh in (16, 32, 64, 128, 256)
         self.use_steps = can and (mode == "1" or (mode == "auto" and D >= 256))
         self.planes = self._build_planes(w, p) if self.use_steps else None
         self._graphs = {}
+        # persistent single-launch decode for small batches (csrc/faceformer_persist.hip): AVI_FF_PERSIST=0 switches it off
+        self.use_persist = (self.use_steps and D in (256, 512, 1024) and os.environ.get("AVI_FF_PERSIST", "1") != "0"
+                            and self.device.type == "cuda"
+                            and torch.cuda.get_device_properties(self.device).multi_processor_count >= 256)
+        # rows per persistent launch: the kernel takes 2, but its stages run the rows one after the other and the second
+        # row costs more than the launch chain charges for it (44.6 vs 41.9 us per frame at D = 1024): 1 unless asked
+        self.persist_rows = int(os.environ.get("AVI_FF_PERSIST_ROWS", "1"))
+        self._persist = None
+        self.last_fallback = None
 
     def _build_planes(self, w, p):
         """Derived constants of the launch-chain path (include/avi_talking.h AviFaceformerPlanes): fragment-major bf16
@@ -171,7 +183,23 @@ class Faceformer:
             raise ValueError("chunk must be a positive multiple of the PPE period")
         return min(chunk, T)
 
-    def decode(self, hidden_states, chunk=None, out_dtype=torch.float32):
+
+    def decode_checked(self, hidden_states, chunk=None, out_dtype=torch.float32):
+        """``decode`` with the persistent kernel's safety net: synchronises, and if a workgroup of the persistent launch
+        timed out on an exchange (it did not get all 256 CUs: output NaN, ``status.EXCHANGE_TIMEOUT``) decodes again on the
+        launch chain.  ``last_fallback`` says whether that happened."""
+        from . import status
+        self.last_fallback = None
+        out = self.decode(hidden_states, chunk=chunk, out_dtype=out_dtype)
+        torch.cuda.synchronize(self.device)
+        status.words()
+        if status._view[status.EXCHANGE_TIMEOUT]:
+            status.clear_word(status.EXCHANGE_TIMEOUT)
+            self.last_fallback = "launch chain"
+            out = self.decode(hidden_states, chunk=chunk, out_dtype=out_dtype, no_persist=True)
+        return out
+
+    def decode(self, hidden_states, chunk=None, out_dtype=torch.float32, no_persist=False):
         """The autoregressive loop of ``predict`` (:710-729) for memory ``hidden_states`` (B,T,D).  ``chunk``: attention
         window for long-form decoding (None = the reference's full causal window, T <= 600).  ``out_dtype`` float16: the
         frame-writing kernel stores IEEE half (BASELINE.json configs[4] "fp16 coeffs"; the fed-back frame stays fp32)."""
@@ -184,6 +212,8 @@ class Faceformer:
         chunk = self._chunk(T, chunk)
         cross = ops.linear(ops.linear(hs, self.cross_v, prec=self.prec), self.cross_o, prec=self.prec)
         if self.use_steps:
+            if self.use_persist and not no_persist and B <= min(self.persist_rows, 2) and 6 * T + 6 < 65535 and chunk <= 1024:
+                return self._decode_persistent(cross, B, T, chunk, out_dtype=out_dtype)
             return self._decode_steps(cross, B, T, chunk, out_dtype=out_dtype)
         kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
         out = torch.empty((B, T, self.V), dtype=out_dtype, device=self.device)
@@ -191,6 +221,52 @@ class Faceformer:
         L.check(fn(C.byref(self.cw), cross.data_ptr(), B, T, chunk, kv.data_ptr(), out.data_ptr(), L.stream_ptr()),
                 "avi_faceformer_decode_chunked")
         return out
+
+    def _decode_persistent(self, cross, B, T, chunk, out_dtype=torch.float32):
+        """Small batches of a wide decoder: one persistent launch (+ the epoch bump), captured per (B, T, chunk)."""
+        from . import status
+        so = L.load()
+        status.words()                                   # the kernel reports a timed-out exchange there
+        if self._persist is None:
+            nimg, nx = C.c_longlong(), C.c_longlong()
+            L.check(so.avi_faceformer_persist_sizes(self.D, C.byref(nimg), C.byref(nx)), "avi_faceformer_persist_sizes")
+            image = torch.empty(nimg.value, dtype=torch.float32, device=self.device)
+            L.check(so.avi_faceformer_persist_pack(C.byref(self.cw), C.byref(self.planes), image.data_ptr(), L.stream_ptr()),
+                    "avi_faceformer_persist_pack")
+            self._persist = dict(image=image, xch=torch.zeros(nx.value // 8, dtype=torch.int64, device=self.device))
+        P = self._persist
+        key = ("persist", B, T, chunk, out_dtype)
+        g = self._graphs.pop(key, None)
+        if g is not None:
+            self._graphs[key] = g
+        if g is None:
+            st = dict(cross=torch.empty((B, T, self.D), dtype=torch.float32, device=self.device),
+                      kv=torch.empty((B, T, 2 * self.D), dtype=torch.float32, device=self.device),
+                      out=torch.empty((B, T, self.V), dtype=out_dtype, device=self.device))
+            half = out_dtype == torch.float16
+
+            def launch():
+                L.check(so.avi_faceformer_decode_persistent(C.byref(self.cw), C.byref(self.planes), P["image"].data_ptr(),
+                                                            st["cross"].data_ptr(), B, T, chunk, st["kv"].data_ptr(),
+                                                            P["xch"].data_ptr(), None if half else st["out"].data_ptr(),
+                                                            st["out"].data_ptr() if half else None, L.stream_ptr()),
+                        "avi_faceformer_decode_persistent")
+            if torch.cuda.is_current_stream_capturing():
+                st["cross"].copy_(cross)
+                launch()
+                return st["out"].clone()
+            st["cross"].copy_(cross)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch()
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            g = self._graphs[key] = (graph, st)
+        graph, st = g
+        st["cross"].copy_(cross)
+        graph.replay()
+        return st["out"].clone()
 
     def _decode_steps(self, cross, B, T, chunk, rows_per_call=32, out_dtype=torch.float32):
         """Wide decoders: the per-frame launch chain, one hipGraph per (rows, T, chunk) over static buffers, replayed

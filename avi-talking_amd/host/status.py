@@ -13,8 +13,9 @@ import torch
 
 from .. import lib as L
 
-F16_OVERFLOW, F16_TINY, PAIR_TIMEOUT, WORDS = 0, 1, 2, 4
+F16_OVERFLOW, F16_TINY, PAIR_TIMEOUT, EXCHANGE_TIMEOUT, WORDS = 0, 1, 2, 3, 4
 FAULT_PAIR_PARTNER_ABSENT = 1
+FAULT_EXCHANGE_ABSENT = 2
 
 _words = None
 _view = None       # numpy view of the same pinned memory: reading it dispatches no torch operator at all
@@ -26,6 +27,10 @@ class RangeError(RuntimeError):
 
 class PairTimeout(RuntimeError):
     """A paired-sampler workgroup gave up on its partner; that pass's style (and coefficients) are NaN."""
+
+
+class ExchangeTimeout(RuntimeError):
+    """A workgroup of the persistent FaceFormer decode never saw a granule it waited for; that decode's output is NaN."""
 
 
 def words():
@@ -60,10 +65,16 @@ def raise_if_set(clear_after=True):
     """Raise for whatever has been reported so far (PairTimeout before RangeError: its results are NaN).  The words are
     cleared first, so one failure raises once and the object stays usable (``clear_after=False`` keeps them)."""
     ovf, tiny, pair = read()
-    if not (ovf or tiny or pair):
+    xch = bool(_view[EXCHANGE_TIMEOUT])
+    if not (ovf or tiny or pair or xch):
         return
     if clear_after:
         clear()
+    if xch:
+        raise ExchangeTimeout("persistent FaceFormer decode: a workgroup never saw a granule it waited for within the bounded "
+                              "spin (the launch needs all 256 CUs free); that decode's output is NaN "
+                              "(csrc/faceformer_persist.hip).  Faceformer.decode_checked() re-runs such a decode on the "
+                              "launch chain; AVI_FF_PERSIST=0 never uses the persistent kernel")
     if pair:
         raise PairTimeout("paired DDPM sampler: a workgroup's partner never answered within the bounded spin; the style of "
                           "that pass is NaN (csrc/prior_pair.hip).  SamplingPipeline.run_checked() re-runs such a batch on "

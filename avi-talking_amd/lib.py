@@ -158,6 +158,9 @@ SIGNATURES = {
     "avi_rng_advance": [_vp, C.c_ulonglong, _vp],
     "avi_faceformer_tf_embed": [_vp, _vp, _i, _i, _vp, _vp],
     "avi_faceformer_steps_work_floats": [_i, _i, C.POINTER(_ll)],
+    "avi_faceformer_persist_sizes": [_i, C.POINTER(_ll), C.POINTER(_ll)],
+    "avi_faceformer_persist_pack": [_vp, _vp, _vp, _vp],
+    "avi_faceformer_decode_persistent": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "avi_faceformer_decode_steps": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "avi_layernorm_ex": [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp],
     "avi_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

