@@ -6,19 +6,21 @@
 // re-fetches its weight slice through the fabric, then waits for its inputs, then drains - 40 us per frame for 22 MB of
 // weights that never change.  Here the weights never move: 256 workgroups, one per CU (the launch needs all 256 CUs of an
 // MI355X free: 133 KB of LDS each), and workgroup g keeps ITS rows of every matrix in LDS for the whole decode, in fp32:
-//     fused q/k/v map  3D/256 columns x 64      out_proj | vertice_map  D/256 rows x (D + 64)
-//     linear1          2D/256 rows x D          linear2                 D/256 rows x 2D          vertice_map_r  1 row (g < 64)
-// (90 KB at D = 1024).  What moves between CUs is the frame's activation vectors, as data-tagged 8-byte granules
+//     q/k/v from LN3's output  3D/256 rows x D  (in_proj . vertice_map . vertice_map_r folded into one matrix: the next
+//                              frame's q, k, v straight from this frame's last LayerNorm, not through the 53 coefficients)
+//     out_proj | vertice_map   D/256 rows x (D + 64)        linear1  2D/256 rows x D        linear2  D/256 rows x 2D
+//     vertice_map_r            1 row (workgroups 64..127: the coefficients themselves, off the critical path)
+// (137 KB at D = 1024).  What moves between CUs is the frame's activation vectors, as data-tagged 8-byte granules
 // {value, tag} in device memory (one relaxed agent-scope store each, polled with relaxed agent-scope loads; the mechanism of
 // prior_pair.hip): tag = launch epoch << 16 | (6 frame + edge + 1), so a granule says by itself whether it is the one
-// awaited - no flags, no fences, no barrier.  Six edges per frame:
-//     o_{i-1} (64)  ->  A  every workgroup: its 3D/256 columns of q, k, v                                   -> QKV
+// awaited - no flags, no fences, no barrier.  Five edges on a frame's critical path, a sixth beside it:
+//     S3 (frame i-1) -> A  every workgroup: y = LN3(s3) (whole row, redundantly), its 3D/256 columns of q, k, v          -> QKV
+//                          workgroups 64..127 then: one coefficient each of frame i-1 (vertice_map_r y), the frame's output -> O
 //     QKV           ->  B  16 workgroups (head h, key residue s = j mod 4): softmax partial (m, l, acc) over ITS keys of the
 //                          cache (it alone ever reads them: plain loads, its own L2), key i appended by residue i mod 4   -> PART
-//     PART          ->  C  every workgroup: merge of the 16 partials, its rows of s1 = x + out_proj(att)    -> S1
+//     PART, O       ->  C  every workgroup: merge of the 16 partials, its rows of s1 = x + out_proj(att), x from O      -> S1
 //     S1            ->  D  every workgroup: x2 = LN2(LN1(s1) + cross_i) (whole rows, redundantly), its rows of relu(linear1) -> H
 //     H             ->  E  every workgroup: its rows of s3 = x2 + linear2(h)                                -> S3
-//     S3            ->  F  workgroups 0..63: LN3, one coefficient each (vertice_map_r), the frame's output   -> O
 // Every spin is bounded: a workgroup that never sees a granule (the launch did not get all its CUs, a foreign kernel holds
 // one) gives up ONCE, takes NaN from then on - so does everything downstream, with correct tags, nobody else stalls - and
 // raises AVI_STATUS_EXCHANGE_TIMEOUT; the launch always drains.  Arithmetic: fp32 multiply-adds on fp32 weights (the launch
@@ -27,7 +29,7 @@
 
 namespace {
 
-constexpr int NT = 256, NH = 4, VP = 64, PB = 2, NWG = 256, KSP = 4, NATT = NH * KSP, NEDGE = 6, KEYMAX = 256, PF = 16;
+constexpr int NT = 256, NH = 4, VP = 64, PB = 1, NWG = 256, MAPR0 = 64, KSP = 4, NATT = NH * KSP, NEDGE = 6, KEYMAX = 256, PF = 16;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 constexpr int XCH_HDR = 8;                // header words (u64): [0] launch epoch
 enum { E_QKV = 0, E_PART = 1, E_S1 = 2, E_H = 3, E_S3 = 4, E_O = 5 };
@@ -35,7 +37,7 @@ enum { E_QKV = 0, E_PART = 1, E_S1 = 2, E_H = 3, E_S3 = 4, E_O = 5 };
 struct Geo {
     int D, dh, nq, no, n1, n2;          // rows of each matrix a workgroup owns
     int sq, so, s1, s2;                 // padded row strides (floats): + 32 so that two rows met by one wave sit 32 banks apart
-    int oq, oo, o1, o2, orr, img;       // offsets of the slices in the image, and its size (floats)
+    int oq, oo, o1, o2, orr, ocq, img;  // offsets of the slices in the image, and its size (floats)
     long long xq, xp, xs1, xh, xs3, xo, xpar;   // exchange offsets (granules) inside one parity, size of a parity
     int ps;                             // granules of one partial: [0] m, [1] l, [4 + d] acc
 };
@@ -43,13 +45,14 @@ __host__ __device__ inline Geo geo(int D) {
     Geo g;
     g.D = D, g.dh = D / NH;
     g.nq = 3 * D / NWG, g.no = D / NWG, g.n1 = 2 * D / NWG, g.n2 = D / NWG;
-    g.sq = VP, g.so = D + VP + 32, g.s1 = D + 32, g.s2 = 2 * D + 32;
+    g.sq = D + 32, g.so = D + VP + 32, g.s1 = D + 32, g.s2 = 2 * D + 32;
     g.oq = 0;
     g.oo = g.oq + g.nq * g.sq;
     g.o1 = g.oo + g.no * g.so;
     g.o2 = g.o1 + g.n1 * g.s1;
     g.orr = g.o2 + g.n2 * g.s2;
-    g.img = g.orr + D;
+    g.ocq = g.orr + D;                  // [16]: constant part of my q/k/v columns
+    g.img = g.ocq + 16;
     g.ps = g.dh + 4;
     g.xq = 0;
     g.xp = g.xq + (long long)PB * 3 * D;
@@ -102,7 +105,7 @@ __device__ __forceinline__ float settle(const unsigned long long* p, unsigned lo
             x.dead = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (spins > 64) __builtin_amdgcn_s_sleep(1);
         gr = peek(p);
     }
     return x.dead ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)gr);
@@ -161,18 +164,19 @@ __device__ __forceinline__ void poll_regs(const unsigned long long* src, long lo
         }
 }
 
-// res[b * 16 + r] = sum_k W[r * ws + k] x[b * xs + k] for r < R = 1 << rs (R <= 8) and b < BT; K % 4 == 0; every thread takes
-// part; ends with a barrier.  NT / R consecutive lanes share a row and read it as float4: conflict-free LDS reads of W,
+// res[b * 16 + r] = sum_k W[r * ws + k] x[b * xs + k] for r < R = 1 << rs (R <= 16; rows >= nrow repeat row nrow - 1) and
+// b < BT; K % 4 == 0; every thread takes part.  Returns the sum to thread (b << rs) + r (others: 0), also left in `res` after a
+// barrier when rows are narrower than a wave (the summing lanes are other threads then).  NT / R consecutive lanes share a row and read it as float4: conflict-free LDS reads of W,
 // broadcast reads of x.  `red` slots [slot, slot + BT) are used when a row spans whole waves.
 template <int BT>
-__device__ __forceinline__ void gemv(const float* __restrict__ W, int ws, int rs, int K, const float* __restrict__ x, int xs,
-                                     float (*red)[4], int slot, float* __restrict__ res) {
+__device__ __forceinline__ float gemv(const float* __restrict__ W, int ws, int rs, int nrow, int K, const float* __restrict__ x,
+                                     int xs, float (*red)[4], int slot, float* __restrict__ res) {
     const int tid = threadIdx.x, lsh = 8 - rs, lpr = 1 << lsh, r = tid >> lsh, l = tid & (lpr - 1), K4 = K >> 2;
     float a[BT];
 #pragma unroll
     for (int b = 0; b < BT; ++b) a[b] = 0.f;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(W + r * ws);
-#pragma unroll 4
+    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (r < nrow ? r : nrow - 1) * ws);
+#pragma unroll 8
     for (int k = l; k < K4; k += lpr) {
         const f32x4 wv = wr[k];
 #pragma unroll
@@ -189,13 +193,13 @@ __device__ __forceinline__ void gemv(const float* __restrict__ W, int ws, int rs
             if ((tid & 63) == 0) red[slot + b][tid >> 6] = w;
         }
         __syncthreads();
+        float sum = 0.f;
         if (tid < (BT << rs)) {
             const int rr = tid & ((1 << rs) - 1), b = tid >> rs;
-            float sum = 0.f;
             for (int q = 0; q < (1 << wsh); ++q) sum += red[slot + b][(rr << wsh) + q];
-            res[b * 16 + rr] = sum;
         }
-    } else {                                 // lpr == 32: two rows per wave
+        return sum;
+    } else if (lsh == 5) {                   // two rows per wave
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
             float lo, hi;
@@ -205,8 +209,17 @@ __device__ __forceinline__ void gemv(const float* __restrict__ W, int ws, int rs
                 res[b * 16 + r + 1] = hi;
             }
         }
+    } else {                                 // lsh == 4: a row is one 16-lane DPP row
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            float v = quad_sum(a[b]);
+            v += FFP_DPP(v, 0x141, 0xF);     // row_half_mirror
+            v += FFP_DPP(v, 0x140, 0xF);     // row_mirror
+            if (l == 0) res[b * 16 + r] = v;
+        }
     }
     __syncthreads();
+    return tid < (BT << rs) ? res[(tid >> rs) * 16 + (tid & ((1 << rs) - 1))] : 0.f;
 }
 
 // AVI_FFP_STAMPS (diagnostic build, scripts/ffp_stamps.py): thread 0 of workgroups 0 and 200 adds up the time (100 MHz ticks)
@@ -264,12 +277,63 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
     }
     const int ro = tid & (G.no - 1), r1 = tid & (G.n1 - 1), r2 = tid & (G.n2 - 1);    // my row when tid < BT * rows
     const float bias_o = c.w.bo[g * G.no + ro], bias_m = c.w.bm[g * G.no + ro], bias_1 = c.w.b1[g * G.n1 + r1];
-    const float bias_2 = c.w.b2[g * G.n2 + r2], bias_r = g < c.w.V ? c.w.br[g] : 0.f;
+    const int gm = g - MAPR0;                               // workgroups MAPR0 .. MAPR0 + 63: coefficient gm of every frame
+    const bool mapr = gm >= 0 && gm < VP;
+    const float bias_2 = c.w.b2[g * G.n2 + r2], bias_r = (mapr && gm < c.w.V) ? c.w.br[gm] : 0.f;
     const int rso = 31 - __builtin_clz(G.no), rs1 = 31 - __builtin_clz(G.n1), rs2 = 31 - __builtin_clz(G.n2);
+    const int rsq = 32 - __builtin_clz(G.nq - 1);           // rows of the q/k/v slice rounded up to a power of two (3, 6, 12)
     __syncthreads();
 #ifdef AVI_FFP_STAMPS
     long long stamp_acc[16] = {0}, stamp_last = wall_clock64();
 #endif
+
+    // y = LN3(s3 of frame f) for my E columns -> vec[0 .. D) (every workgroup, redundantly); ends with a barrier
+    auto last_norm = [&](int f) __attribute__((always_inline)) {
+        float t[BT][E];
+        poll_regs<BT, E>(xbase + (long long)(f & 1) * G.xpar + G.xs3, D, D, ((epoch << 16) | (unsigned)(f * NEDGE + 1)) + E_S3, x, t);
+        FFP_STAMP(0);       // waited for s3 of the previous frame
+        const float invD = 1.f / D;
+        float sm[BT], sq[BT];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            sm[b] = 0.f;
+#pragma unroll
+            for (int u = 0; u < E; ++u) sm[b] += t[b][u];
+        }
+        block_reduce<BT, false>(sm, red, 4 + 4 * PB);
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            sq[b] = 0.f;
+#pragma unroll
+            for (int u = 0; u < E; ++u)
+                if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
+        }
+        block_reduce<BT, false>(sq, red, 4 + 5 * PB);
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < E; ++u)
+                if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = (t[b][u] - mu) * rs * g3[u] + b3n[u];
+        }
+        __syncthreads();
+    };
+    // coefficient gm of frame f from y in vec (workgroups MAPR0 ..): published for frame f + 1's out-projection, and written out
+    auto emit_coeff = [&](int f) __attribute__((always_inline)) {
+        const float ysum = gemv<BT>(img + G.orr, D, 0, 1, D, vec, 2 * D, red, 2, res);
+        if (tid < BT) {
+            const bool real = gm < c.w.V;
+            float v = real ? ysum + bias_r : 0.f;
+            // normalised: what vertice_map feeds back (:722-725)
+            publish(xbase + (long long)(f & 1) * G.xpar + G.xo + (long long)tid * VP + gm, v, ((epoch << 16) | (unsigned)(f * NEDGE + 1)) + E_O);
+            if (real) {
+                if (c.w.coeff_std) v = v * c.w.coeff_std[gm] + c.w.coeff_mean[gm];       // :729
+                const long long oi2 = ((long long)tid * c.T + f) * c.w.V + gm;
+                if (c.out16) c.out16[oi2] = __builtin_bit_cast(uint16_t, (_Float16)v);
+                else c.out[oi2] = v;
+            }
+        }
+    };
 
     for (int i = 0; i < c.T; ++i) {
         const int phase = i % c.w.period;
@@ -287,27 +351,16 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             }
         const float pe_o = i == 0 ? c.p.x0[g * G.no + ro] : bias_m + c.w.pe[(long long)phase * D + g * G.no + ro];
 
-        // ---- A: my columns of q, k, v from the previous coefficient frame ----------------------------------------------
-        const int oi = tid >> 2, part = tid & 3, bq = oi / G.nq, rq = oi - bq * G.nq;      // output (row bq, column rq), quarter
-        const bool qon = oi < BT * G.nq;
-        const float bfq = i == 0 ? (qon ? c.p.qkv0[g * G.nq + rq] : 0.f)
-                                 : (qon ? c.p.bf[(long long)phase * 3 * D + g * G.nq + rq] : 0.f);
-        if (i > 0 && tid < BT * VP) {
-            const unsigned long long* p = xbase + (long long)((i - 1) & 1) * G.xpar + G.xo + tid;
-            ov[tid] = settle(p, x.dead ? 0ull : peek(p), tb - NEDGE + E_O, x);
-        }
-        __syncthreads();
-        FFP_STAMP(0);       // waited for o_{i-1}
-        {
-            float a = 0.f;
-            if (i > 0 && qon) {
-                const float* wq = img + G.oq + rq * G.sq + part * 16;
-                const float* o = ov + bq * VP + part * 16;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) a = fmaf(wq[v], o[v], a);
-            }
-            a = quad_sum(a);
-            if (qon && part == 0) publish(X + G.xq + (long long)bq * 3 * D + g * G.nq + rq, bfq + a, tb + E_QKV);
+        // ---- A: my columns of q, k, v, straight from the previous frame's last LayerNorm ---------------------------------
+        const float bfq = tid < G.nq ? (i == 0 ? c.p.qkv0[g * G.nq + tid] : c.p.bf[(long long)phase * 3 * D + g * G.nq + tid] + img[G.ocq + tid])
+                                     : 0.f;
+        if (i == 0) {
+            if (tid < G.nq) publish(X + G.xq + g * G.nq + tid, bfq, tb + E_QKV);
+        } else {
+            last_norm(i - 1);
+            const float qsum = gemv<BT>(img + G.oq, G.sq, rsq, G.nq, D, vec, 2 * D, red, 2, res);
+            if (tid < G.nq) publish(X + G.xq + g * G.nq + tid, qsum + bfq, tb + E_QKV);
+            if (mapr) emit_coeff(i - 1);
         }
         FFP_STAMP(1);       // q/k/v columns
 
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             const int nk = i >= j0 ? (i - j0) / KSP + 1 : 0;
             const bool owner = (i % KSP) == s;                            // then my LAST key is frame i itself
             const int LPK = dh >> 2, lpsh = dsh - 2, groups = NT >> lpsh, gk = tid >> lpsh, l = tid & (LPK - 1);
-            const int nd4 = dh >> 4;                                      // float4s of a key a score thread covers (<= 16)
+            const int nd4 = dh >> 4, part = tid & 3;                      // float4s of a key a score thread covers (<= 16)
             const float slope = c.w.slopes[h];
             for (int b = 0; b < BT; ++b) {
                 float* kvb = c.kv + (long long)b * c.T * 2 * D;
@@ -417,7 +470,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                     publish(Xp + 0, nk > 0 ? mx[0] : -3.0e38f, tb + E_PART);
                     publish(Xp + 1, nk > 0 ? sum[0] : 0.f, tb + E_PART);
                 }
-                __syncthreads();                       // qs / ks / vs / sc / accr are free for the next row
+                if (b + 1 < BT) __syncthreads();       // qs / ks / vs / sc / accr are free for the next row
             }
         }
         FFP_STAMP(2);       // attention (workgroups 0..15)
@@ -463,14 +516,21 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                     }
                 }
         }
-        if (tid < BT * VP) vec[(tid / VP) * 2 * D + D + (tid % VP)] = i > 0 ? ov[tid] : 0.f;     // [att | o_{i-1}]
+        if (tid < BT * VP) {                                                                     // [att | o_{i-1}]
+            float o = 0.f;
+            if (i > 0) {
+                const unsigned long long* p = xbase + (long long)((i - 1) & 1) * G.xpar + G.xo + tid;
+                o = settle(p, x.dead ? 0ull : peek(p), tb - NEDGE + E_O, x);
+            }
+            vec[(tid / VP) * 2 * D + D + (tid % VP)] = o;
+        }
         __syncthreads();
         FFP_STAMP(3);       // waited for the partials, merged them
-        gemv<BT>(img + G.oo, G.so, rso, D + VP, vec, 2 * D, red, 2, res);
+        const float osum = gemv<BT>(img + G.oo, G.so, rso, G.no, D + VP, vec, 2 * D, red, 2, res);
         if (tid < BT * G.no) {
             // x = vertice_map(o_{i-1}) + pe_i (frame 0: obj_embedding + pe_0); the vertice_map product came out of the same rows
             const int bb = tid >> rso;
-            publish(X + G.xs1 + (long long)bb * D + g * G.no + ro, res[bb * 16 + ro] + bias_o + pe_o, tb + E_S1);
+            publish(X + G.xs1 + (long long)bb * D + g * G.no + ro, osum + bias_o + pe_o, tb + E_S1);
         }
         FFP_STAMP(4);       // out-projection rows
 
@@ -516,10 +576,10 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         }
         FFP_STAMP(6);       // two LayerNorms
         const float x2own = tid < BT * G.n2 ? vec[(tid >> rs2) * 2 * D + g * G.n2 + r2] : 0.f;   // linear2's residual, my rows
-        gemv<BT>(img + G.o1, G.s1, rs1, D, vec, 2 * D, red, 2, res);
+        const float hsum = gemv<BT>(img + G.o1, G.s1, rs1, G.n1, D, vec, 2 * D, red, 2, res);
         if (tid < BT * G.n1) {
             const int bb = tid >> rs1;
-            publish(X + G.xh + (long long)bb * 2 * D + g * G.n1 + r1, fmaxf(res[bb * 16 + r1] + bias_1, 0.f), tb + E_H);
+            publish(X + G.xh + (long long)bb * 2 * D + g * G.n1 + r1, fmaxf(hsum + bias_1, 0.f), tb + E_H);
         }
         FFP_STAMP(7);       // linear1 rows
 
@@ -535,58 +595,17 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             __syncthreads();
         }
         FFP_STAMP(8);       // waited for h
-        gemv<BT>(img + G.o2, G.s2, rs2, 2 * D, vec, 2 * D, red, 2, res);
+        const float ssum = gemv<BT>(img + G.o2, G.s2, rs2, G.n2, 2 * D, vec, 2 * D, red, 2, res);
         if (tid < BT * G.n2) {
             const int bb = tid >> rs2;
-            publish(X + G.xs3 + (long long)bb * D + g * G.n2 + r2, x2own + bias_2 + res[bb * 16 + r2], tb + E_S3);
+            publish(X + G.xs3 + (long long)bb * D + g * G.n2 + r2, x2own + bias_2 + ssum, tb + E_S3);
         }
         FFP_STAMP(9);       // linear2 rows
 
-        // ---- F: coefficient g of the frame (workgroups 0..63) ----------------------------------------------------------
-        if (g < VP) {
-            float t[BT][E];
-            poll_regs<BT, E>(X + G.xs3, D, D, tb + E_S3, x, t);
-            FFP_STAMP(10);  // waited for s3
-            const float invD = 1.f / D;
-            float sm[BT], sq[BT];
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                sm[b] = 0.f;
-#pragma unroll
-                for (int u = 0; u < E; ++u) sm[b] += t[b][u];
-            }
-            block_reduce<BT, false>(sm, red, 4 + 4 * PB);
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                sq[b] = 0.f;
-#pragma unroll
-                for (int u = 0; u < E; ++u)
-                    if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
-            }
-            block_reduce<BT, false>(sq, red, 4 + 5 * PB);
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
-#pragma unroll
-                for (int u = 0; u < E; ++u)
-                    if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = (t[b][u] - mu) * rs * g3[u] + b3n[u];
-            }
-            __syncthreads();
-            FFP_STAMP(11);  // LayerNorm 3
-            gemv<BT>(img + G.orr, D, 0, D, vec, 2 * D, red, 2, res);
-            if (tid < BT) {
-                const bool real = g < c.w.V;
-                float v = real ? res[tid * 16] + bias_r : 0.f;
-                publish(X + G.xo + (long long)tid * VP + g, v, tb + E_O);      // normalised: what vertice_map feeds back (:722-725)
-                if (real) {
-                    if (c.w.coeff_std) v = v * c.w.coeff_std[g] + c.w.coeff_mean[g];       // :729
-                    const long long oi2 = ((long long)tid * c.T + i) * c.w.V + g;
-                    if (c.out16) c.out16[oi2] = __builtin_bit_cast(uint16_t, (_Float16)v);
-                    else c.out[oi2] = v;
-                }
-            }
-            FFP_STAMP(12);  // vertice_map_r row, frame out
-        }
+    }
+    if (mapr) {             // the last frame's coefficients
+        last_norm(c.T - 1);
+        emit_coeff(c.T - 1);
     }
 #ifdef AVI_FFP_STAMPS
     __syncthreads();
@@ -616,9 +635,10 @@ __global__ __launch_bounds__(NT) void ff_persist_pack_kernel(const AviFaceformer
     float* im = image + (long long)g * G.img;
     for (int i = threadIdx.x; i < G.img; i += NT) {
         float v = 0.f;
-        if (i < G.oo) {                       // fused q/k/v map: [nq][64], column g nq + r of wf_t [64][3D]
-            const int r = i / G.sq, k = i - r * G.sq;
-            v = p.wf_t[(long long)k * 3 * D + g * G.nq + r];
+        if (i < G.oo) {                       // q/k/v from LN3's output: row c = g nq + r of (wf_t^T . wr^T), [3D][D]
+            const int r = i / G.sq, k = i - r * G.sq, col = g * G.nq + r;
+            if (k < D)
+                for (int vv = 0; vv < w.V; ++vv) v = fmaf(p.wf_t[(long long)vv * 3 * D + col], w.wr[(long long)k * w.V + vv], v);
         } else if (i < G.o1) {                // [out_proj | vertice_map] row n: wo [K = D][N = D], wm [V][D]
             const int q = i - G.oo, r = q / G.so, k = q - r * G.so, n = g * G.no + r;
             if (k < D) v = w.wo[(long long)k * D + n];
@@ -629,9 +649,13 @@ __global__ __launch_bounds__(NT) void ff_persist_pack_kernel(const AviFaceformer
         } else if (i < G.orr) {               // linear2 row n: w2 [2D][D]
             const int q = i - G.o2, r = q / G.s2, k = q - r * G.s2;
             if (k < 2 * D) v = w.w2[(long long)k * D + g * G.n2 + r];
-        } else {                              // vertice_map_r row g: wr [D][V]
-            const int k = i - G.orr;
-            if (g < w.V) v = w.wr[(long long)k * w.V + g];
+        } else if (i < G.ocq) {               // vertice_map_r row g - MAPR0: wr [D][V]
+            const int k = i - G.orr, gm = g - MAPR0;
+            if (gm >= 0 && gm < w.V) v = w.wr[(long long)k * w.V + gm];
+        } else {                              // constant part of my q/k/v columns: wf_t^T . br
+            const int r = i - G.ocq, col = g * G.nq + r;
+            if (r < G.nq)
+                for (int vv = 0; vv < w.V; ++vv) v = fmaf(p.wf_t[(long long)vv * 3 * D + col], w.br[vv], v);
         }
         im[i] = v;
     }
@@ -654,7 +678,7 @@ extern "C" int avi_faceformer_persist_sizes(int D, long long* image_floats, long
 extern "C" int avi_faceformer_persist_pack(const AviFaceformerWeights* w, const AviFaceformerPlanes* p, float* image,
                                            void* stream) {
     if (!w || !p || !image || !persist_shape_ok(w->D) || w->V < 1 || w->V > VP) return AVI_EINVAL;
-    if (!w->wo || !w->w1 || !w->w2 || !w->wr || !w->wm || !p->wf_t) return AVI_EINVAL;
+    if (!w->wo || !w->w1 || !w->w2 || !w->wr || !w->wm || !w->br || !p->wf_t) return AVI_EINVAL;
     if (reinterpret_cast<uintptr_t>(image) & 15) return AVI_EINVAL;
     hipLaunchKernelGGL(ff_persist_pack_kernel, dim3(NWG), dim3(NT), 0, static_cast<hipStream_t>(stream), *w, *p, image);
     return avi_launch_status();
@@ -680,9 +704,8 @@ extern "C" int avi_faceformer_decode_persistent(const AviFaceformerWeights* w, c
         return AVI_EINVAL;                                                  // one workgroup per CU, all resident at once
     const Geo G = geo(w->D);
     const int smem = lds_floats(G) * (int)sizeof(float);
-    static AviLdsGrant grant1, grant2;
+    static AviLdsGrant grant1;
     grant1.ensure(reinterpret_cast<const void*>(ff_persist_kernel<1>), 160 * 1024);
-    grant2.ensure(reinterpret_cast<const void*>(ff_persist_kernel<2>), 160 * 1024);
     if (smem > 160 * 1024) return AVI_EINVAL;
     Persist c;
     c.w = *w, c.p = *p, c.image = image, c.cross = cross, c.kv = kv_scratch, c.out = out, c.out16 = out16;
@@ -691,8 +714,7 @@ extern "C" int avi_faceformer_decode_persistent(const AviFaceformerWeights* w, c
     c.B = B, c.T = T, c.D = w->D, c.chunk = chunk;
     c.fault = avi_fault_injected() & AVI_FAULT_EXCHANGE_ABSENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (B == 1) hipLaunchKernelGGL(ff_persist_kernel<1>, dim3(NWG), dim3(NT), smem, s, c);
-    else hipLaunchKernelGGL(ff_persist_kernel<2>, dim3(NWG), dim3(NT), smem, s, c);
+    hipLaunchKernelGGL(ff_persist_kernel<1>, dim3(NWG), dim3(NT), smem, s, c);
     hipLaunchKernelGGL(ff_persist_epoch_kernel, dim3(1), dim3(256), 0, s, c.xch, 2 * G.xpar);
     return avi_launch_status();
 }

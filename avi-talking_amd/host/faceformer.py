@@ -14,9 +14,10 @@ decodes B utterances at once with a KV cache.  Two device paths behind ``decode`
   * wide decoders (D >= 256, e.g. feature_dim 1024 of config/vocaset/demo.yaml): a chain of 6-7 small launches per
     frame, each spread over the whole chip (csrc/faceformer_steps.hip), captured once per (B, T, chunk) in a hipGraph
     and replayed;
-  * wide decoders, ONE utterance (two on request) (D in 256 / 512 / 1024): ONE persistent launch of 256 workgroups that keep their
+  * wide decoders, ONE utterance (D in 256 / 512 / 1024): ONE persistent launch of 256 workgroups that keep their
     rows of every matrix in LDS and exchange the frame's vectors as tagged granules (csrc/faceformer_persist.hip); the
-    launch chain is its fallback (``decode_checked``) and the path for larger batches.
+    launch chain is its fallback (``decode_checked``) and the path for batches (a second row costs the persistent kernel
+    more than the chain charges for it: its stages run the rows one after the other).
 Long-form (T > 600, which the reference's tables do not reach: models/faceformer.py:88,147): ``decode(..., chunk=C)``
 selects the chunked-causal window defined in include/avi_talking.h (avi_faceformer_decode_chunked).
 """
@@ -126,11 +127,8 @@ class Faceformer:
         self.use_persist = (self.use_steps and D in (256, 512, 1024) and os.environ.get("AVI_FF_PERSIST", "1") != "0"
                             and self.device.type == "cuda"
                             and torch.cuda.get_device_properties(self.device).multi_processor_count >= 256)
-        # rows per persistent launch: the kernel takes 2, but its stages run the rows one after the other and the second
-        # row costs more than the launch chain charges for it (44.6 vs 41.9 us per frame at D = 1024): 1 unless asked
-        self.persist_rows = int(os.environ.get("AVI_FF_PERSIST_ROWS", "1"))
         self._persist = None
-        self.last_fallback = None
+        self.last_fallback = self._last_path = None
 
     def _build_planes(self, w, p):
         """Derived constants of the launch-chain path (include/avi_talking.h AviFaceformerPlanes): fragment-major bf16
@@ -189,8 +187,10 @@ class Faceformer:
         timed out on an exchange (it did not get all 256 CUs: output NaN, ``status.EXCHANGE_TIMEOUT``) decodes again on the
         launch chain.  ``last_fallback`` says whether that happened."""
         from . import status
-        self.last_fallback = None
+        self.last_fallback = self._last_path = None
         out = self.decode(hidden_states, chunk=chunk, out_dtype=out_dtype)
+        if self._last_path != "persist" or torch.cuda.is_current_stream_capturing():
+            return out                   # the other paths cannot time out (and a capture cannot be synchronised)
         torch.cuda.synchronize(self.device)
         status.words()
         if status._view[status.EXCHANGE_TIMEOUT]:
@@ -212,7 +212,7 @@ class Faceformer:
         chunk = self._chunk(T, chunk)
         cross = ops.linear(ops.linear(hs, self.cross_v, prec=self.prec), self.cross_o, prec=self.prec)
         if self.use_steps:
-            if self.use_persist and not no_persist and B <= min(self.persist_rows, 2) and 6 * T + 6 < 65535 and chunk <= 1024:
+            if self.use_persist and not no_persist and B == 1 and 6 * T + 6 < 65535 and chunk <= 1024:
                 return self._decode_persistent(cross, B, T, chunk, out_dtype=out_dtype)
             return self._decode_steps(cross, B, T, chunk, out_dtype=out_dtype)
         kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
@@ -223,8 +223,9 @@ class Faceformer:
         return out
 
     def _decode_persistent(self, cross, B, T, chunk, out_dtype=torch.float32):
-        """Small batches of a wide decoder: one persistent launch (+ the epoch bump), captured per (B, T, chunk)."""
+        """One utterance of a wide decoder: one persistent launch (+ the epoch bump), captured per (B, T, chunk)."""
         from . import status
+        self._last_path = "persist"
         so = L.load()
         status.words()                                   # the kernel reports a timed-out exchange there
         if self._persist is None:
@@ -396,7 +397,7 @@ class Faceformer:
             if self.cw.coeff_mean:
                 raise RuntimeError("the AR branch of forward() compares NORMALISED coefficients: build the decoder "
                                    "without coeff_mean/std")
-            pred = self.decode(hs)
+            pred = self.decode_checked(hs)
         if criterion is not None:
             return torch.mean(criterion(pred, c) * lip_coeff_weight), pred
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
@@ -407,4 +408,4 @@ class Faceformer:
 
     @torch.no_grad()
     def predict(self, audio, head_img=None, eye_img=None, emotion_img=None, text=None, cond_embeds=None, chunk=None):
-        return self.decode(self._audio_memory(audio, cond_embeds), chunk=chunk)
+        return self.decode_checked(self._audio_memory(audio, cond_embeds), chunk=chunk)

@@ -402,9 +402,9 @@ typedef struct AviFaceformerPlanes {
 } AviFaceformerPlanes;
 /* *floats = size of `work` (in floats) the chain needs for B utterances of width D */
 int avi_faceformer_steps_work_floats(int D, int B, long long* floats);
-/* The same decode for wide decoders and SMALL batches (B <= 2) as ONE persistent launch of 256 workgroups, one per CU
+/* The same decode for wide decoders and ONE utterance (B = 1) as ONE persistent launch of 256 workgroups, one per CU
  * (csrc/faceformer_persist.hip): every workgroup keeps its rows of all five matrices in LDS for the whole decode (fp32:
- * 90 KB at D = 1024) and the frame's activation vectors travel between the CUs as data-tagged 8-byte granules, six edges per
+ * 137 KB at D = 1024) and the frame's activation vectors travel between the CUs as data-tagged 8-byte granules, six edges per
  * frame.  Replaces the per-frame launch chain below where its launches are latency, not work (40 us per frame at B = 1).
  * D in {256, 512, 1024}; 6 T + 6 < 65 535; chunk <= 1024; the device must have >= 256 CUs, all free (AVI_EINVAL otherwise;
  * a launch that does not get them ends with NaN output and AVI_STATUS_EXCHANGE_TIMEOUT, never hangs).

@@ -164,10 +164,10 @@ def test_forward_loss_teacher_forced_and_ar(gpu):
     assert abs(loss_ar.item() - ((ref_ar - coeff[..., :53]) ** 2).mean().item()) < 1e-4
 
 
-@pytest.mark.parametrize("B,T,D,period,chunk", [(1, 64, 1024, 30, None), (2, 45, 256, 30, None), (2, 90, 512, 30, 30),
-                                                (1, 50, 256, 25, None), (1, 130, 1024, 30, 60), (2, 300, 1024, 30, None)])
+@pytest.mark.parametrize("B,T,D,period,chunk", [(1, 64, 1024, 30, None), (1, 45, 256, 30, None), (1, 90, 512, 30, 30),
+                                                (1, 50, 256, 25, None), (1, 130, 1024, 30, 60), (1, 300, 1024, 30, None)])
 def test_persistent_decode_matches_oracle_and_launch_chain(gpu, B, T, D, period, chunk):
-    """Small batches of a wide decoder: ONE persistent launch (csrc/faceformer_persist.hip: weights resident in LDS, six
+    """One utterance of a wide decoder: ONE persistent launch (csrc/faceformer_persist.hip: weights resident in LDS, six
     tagged-granule exchanges per frame) against the cached oracle and against the per-frame launch chain; chunked windows,
     half output, and a second call that replays the captured launch on new inputs (next launch epoch)."""
     from avi_talking_amd.weights import make_faceformer_weights
@@ -178,7 +178,6 @@ def test_persistent_decode_matches_oracle_and_launch_chain(gpu, B, T, D, period,
     ff = Faceformer(w, period=period, device=gpu)
     if not ff.use_persist:
         pytest.skip("the persistent decode needs a device with 256 CUs")
-    ff.persist_rows = 2                  # the default sends two utterances to the launch chain (faster there)
     status.clear()
     for seed in (61, 62):
         hs = torch.randn(B, T, D, generator=torch.Generator().manual_seed(seed))
