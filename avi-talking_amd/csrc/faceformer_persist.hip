@@ -143,6 +143,38 @@ __device__ __forceinline__ void block_reduce(float (&v)[N], float (*red)[4], int
                    : (red[slot + q][0] + red[slot + q][1]) + (red[slot + q][2] + red[slot + q][3]);
 }
 
+// LayerNorm statistics of BT rows whose values sit E per thread in registers (columns past D hold 0): ONE workgroup
+// reduction instead of two (mean, then squares about it).  Every thread takes the squares about the mean of ITS values and
+// the partial (n, mean, M2) triples are merged - sum_i (x_i - m)^2 = sum over threads of [M2_t + n_t (m_t - m)^2] - so the
+// E[x^2] - mean^2 cancellation only touches the spread of the thread means (a quarter of the variance at 4 values per thread).
+template <int BT, int E>
+__device__ __forceinline__ void row_stats(const float (&t)[BT][E], int D, float (*red)[4], int slot, float (&mu)[BT], float (&rs)[BT]) {
+    const int tid = threadIdx.x;
+    float v[3 * BT];                    // per row: sum, sum_t M2_t, sum_t n_t m_t^2
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        float n = 0.f, sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < E; ++u)
+            if (u * NT + tid < D) n += 1.f, sum += t[b][u];
+        const float m = n > 0.f ? sum / n : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < E; ++u)
+            if (u * NT + tid < D) m2 += (t[b][u] - m) * (t[b][u] - m);
+        v[3 * b] = sum, v[3 * b + 1] = m2, v[3 * b + 2] = n * m * m;
+    }
+    block_reduce<3 * BT, false>(v, red, slot);
+    const float invD = 1.f / D;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        mu[b] = v[3 * b] * invD;
+        // sum_t n_t (m_t - mu)^2 = sum_t n_t m_t^2 - D mu^2   (the thread means m_t are O(sigma) apart, not O(mu): mild)
+        const float var = (v[3 * b + 1] + fmaxf(v[3 * b + 2] - v[3 * b] * mu[b], 0.f)) * invD;
+        rs[b] = rsqrtf(var + 1e-5f);
+    }
+}
+
 // element u * NT + tid of row b of a published vector (n <= E * NT values per row, row stride `stride` granules) -> v[b][u]
 template <int BT, int E>
 __device__ __forceinline__ void poll_regs(const unsigned long long* src, long long stride, int n, unsigned tag, Ex& x,
@@ -164,62 +196,34 @@ __device__ __forceinline__ void poll_regs(const unsigned long long* src, long lo
         }
 }
 
-// res[b * 16 + r] = sum_k W[r * ws + k] x[b * xs + k] for r < R = 1 << rs (R <= 16; rows >= nrow repeat row nrow - 1) and
-// b < BT; K % 4 == 0; every thread takes part.  Returns the sum to thread (b << rs) + r (others: 0), also left in `res` after a
-// barrier when rows are narrower than a wave (the summing lanes are other threads then).  NT / R consecutive lanes share a row and read it as float4: conflict-free LDS reads of W,
-// broadcast reads of x.  `red` slots [slot, slot + BT) are used when a row spans whole waves.
-template <int BT>
-__device__ __forceinline__ float gemv(const float* __restrict__ W, int ws, int rs, int nrow, int K, const float* __restrict__ x,
-                                     int xs, float (*red)[4], int slot, float* __restrict__ res) {
-    const int tid = threadIdx.x, lsh = 8 - rs, lpr = 1 << lsh, r = tid >> lsh, l = tid & (lpr - 1), K4 = K >> 2;
-    float a[BT];
+// sums[q] = sum_k W[(wave * rpw + q) * ws + k] x[k] for q < rpw <= RPW: wave w owns rows w rpw .. w rpw + rpw - 1 (rows >= nrow
+// repeat row nrow - 1), a lane takes every 64th float4 of them.  K % 4 == 0.  The sums are wave-uniform: no LDS, no barrier -
+// the lanes q < rpw of each wave publish.
+template <int RPW>
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ W, int ws, int rpw, int nrow, int K,
+                                          const float* __restrict__ x, float (&sums)[RPW]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, K4 = K >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* w4[RPW];
+    float a[RPW];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) a[b] = 0.f;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (r < nrow ? r : nrow - 1) * ws);
-#pragma unroll 8
-    for (int k = l; k < K4; k += lpr) {
-        const f32x4 wv = wr[k];
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            const f32x4 xv = reinterpret_cast<const f32x4*>(x + b * xs)[k];
-            a[b] = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], a[b]))));
-        }
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave * rpw + q;
+        w4[q] = reinterpret_cast<const f32x4*>(W + (r < nrow ? r : nrow - 1) * ws);
+        a[q] = 0.f;
     }
-    if (lsh >= 6) {                          // a row is 1, 2 or 4 whole waves
-        const int wsh = lsh - 6;
+#pragma unroll 4
+    for (int k = lane; k < K4; k += 64) {
+        const f32x4 xv = x4[k];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            const float w = wave_sum_u(a[b]);
-            if ((tid & 63) == 0) red[slot + b][tid >> 6] = w;
-        }
-        __syncthreads();
-        float sum = 0.f;
-        if (tid < (BT << rs)) {
-            const int rr = tid & ((1 << rs) - 1), b = tid >> rs;
-            for (int q = 0; q < (1 << wsh); ++q) sum += red[slot + b][(rr << wsh) + q];
-        }
-        return sum;
-    } else if (lsh == 5) {                   // two rows per wave
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            float lo, hi;
-            half_sums(a[b], lo, hi);
-            if ((tid & 63) == 0) {
-                res[b * 16 + r] = lo;
-                res[b * 16 + r + 1] = hi;
+        for (int q = 0; q < RPW; ++q)
+            if (q < rpw) {
+                const f32x4 wv = w4[q][k];
+                a[q] = fmaf(wv[0], xv[0], fmaf(wv[1], xv[1], fmaf(wv[2], xv[2], fmaf(wv[3], xv[3], a[q]))));
             }
-        }
-    } else {                                 // lsh == 4: a row is one 16-lane DPP row
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            float v = quad_sum(a[b]);
-            v += FFP_DPP(v, 0x141, 0xF);     // row_half_mirror
-            v += FFP_DPP(v, 0x140, 0xF);     // row_mirror
-            if (l == 0) res[b * 16 + r] = v;
-        }
     }
-    __syncthreads();
-    return tid < (BT << rs) ? res[(tid >> rs) * 16 + (tid & ((1 << rs) - 1))] : 0.f;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) sums[q] = q < rpw ? wave_sum_u(a[q]) : 0.f;
 }
 
 // AVI_FFP_STAMPS (diagnostic build, scripts/ffp_stamps.py): thread 0 of workgroups 0 and 200 adds up the time (100 MHz ticks)
@@ -275,13 +279,18 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         g1[u] = c.w.n1g[dd], b1n[u] = c.w.n1b[dd], g2[u] = c.w.n2g[dd], b2n[u] = c.w.n2b[dd];
         g3[u] = c.w.n3g[dd], b3n[u] = c.w.n3b[dd];
     }
-    const int ro = tid & (G.no - 1), r1 = tid & (G.n1 - 1), r2 = tid & (G.n2 - 1);    // my row when tid < BT * rows
-    const float bias_o = c.w.bo[g * G.no + ro], bias_m = c.w.bm[g * G.no + ro], bias_1 = c.w.b1[g * G.n1 + r1];
+    static_assert(BT == 1, "the stages below take one utterance");
+    // rows of each matrix per wave; lane q < rpw of wave w publishes row w rpw + q (if it exists)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rpq = (G.nq + 3) >> 2, rpo = (G.no + 3) >> 2, rp1 = (G.n1 + 3) >> 2, rp2 = (G.n2 + 3) >> 2;
+    const int rowq = wave * rpq + lane, rowo = wave * rpo + lane, row1 = wave * rp1 + lane, row2 = wave * rp2 + lane;
+    const bool pubq = lane < rpq && rowq < G.nq, pubo = lane < rpo && rowo < G.no, pub1 = lane < rp1 && row1 < G.n1,
+               pub2 = lane < rp2 && row2 < G.n2;
+    const float bias_o = pubo ? c.w.bo[g * G.no + rowo] : 0.f, bias_m = pubo ? c.w.bm[g * G.no + rowo] : 0.f;
+    const float bias_1 = pub1 ? c.w.b1[g * G.n1 + row1] : 0.f, bias_2 = pub2 ? c.w.b2[g * G.n2 + row2] : 0.f;
     const int gm = g - MAPR0;                               // workgroups MAPR0 .. MAPR0 + 63: coefficient gm of every frame
     const bool mapr = gm >= 0 && gm < VP;
-    const float bias_2 = c.w.b2[g * G.n2 + r2], bias_r = (mapr && gm < c.w.V) ? c.w.br[gm] : 0.f;
-    const int rso = 31 - __builtin_clz(G.no), rs1 = 31 - __builtin_clz(G.n1), rs2 = 31 - __builtin_clz(G.n2);
-    const int rsq = 32 - __builtin_clz(G.nq - 1);           // rows of the q/k/v slice rounded up to a power of two (3, 6, 12)
+    const float bias_r = (mapr && gm < c.w.V) ? c.w.br[gm] : 0.f;
     __syncthreads();
 #ifdef AVI_FFP_STAMPS
     long long stamp_acc[16] = {0}, stamp_last = wall_clock64();
@@ -292,38 +301,22 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         float t[BT][E];
         poll_regs<BT, E>(xbase + (long long)(f & 1) * G.xpar + G.xs3, D, D, ((epoch << 16) | (unsigned)(f * NEDGE + 1)) + E_S3, x, t);
         FFP_STAMP(0);       // waited for s3 of the previous frame
-        const float invD = 1.f / D;
-        float sm[BT], sq[BT];
+        float mu[BT], rs[BT];
+        row_stats<BT, E>(t, D, red, 4 + 8 * BT, mu, rs);
 #pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            sm[b] = 0.f;
-#pragma unroll
-            for (int u = 0; u < E; ++u) sm[b] += t[b][u];
-        }
-        block_reduce<BT, false>(sm, red, 4 + 4 * PB);
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            sq[b] = 0.f;
+        for (int b = 0; b < BT; ++b)
 #pragma unroll
             for (int u = 0; u < E; ++u)
-                if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
-        }
-        block_reduce<BT, false>(sq, red, 4 + 5 * PB);
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-            const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
-#pragma unroll
-            for (int u = 0; u < E; ++u)
-                if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = (t[b][u] - mu) * rs * g3[u] + b3n[u];
-        }
+                if (u * NT + tid < D) vec[b * 2 * D + u * NT + tid] = (t[b][u] - mu[b]) * rs[b] * g3[u] + b3n[u];
         __syncthreads();
     };
     // coefficient gm of frame f from y in vec (workgroups MAPR0 ..): published for frame f + 1's out-projection, and written out
     auto emit_coeff = [&](int f) __attribute__((always_inline)) {
-        const float ysum = gemv<BT>(img + G.orr, D, 0, 1, D, vec, 2 * D, red, 2, res);
+        float ys[1];
+        gemv_rows<1>(img + G.orr, D, 1, 1, D, vec, ys);
         if (tid < BT) {
             const bool real = gm < c.w.V;
-            float v = real ? ysum + bias_r : 0.f;
+            float v = real ? ys[0] + bias_r : 0.f;
             // normalised: what vertice_map feeds back (:722-725)
             publish(xbase + (long long)(f & 1) * G.xpar + G.xo + (long long)tid * VP + gm, v, ((epoch << 16) | (unsigned)(f * NEDGE + 1)) + E_O);
             if (real) {
@@ -349,17 +342,17 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                 const int d = u * NT + tid;
                 crs[b][u] = d < D ? c.cross[((long long)b * c.T + i) * D + d] : 0.f;
             }
-        const float pe_o = i == 0 ? c.p.x0[g * G.no + ro] : bias_m + c.w.pe[(long long)phase * D + g * G.no + ro];
+        const float pe_o = !pubo ? 0.f : i == 0 ? c.p.x0[g * G.no + rowo] : bias_m + c.w.pe[(long long)phase * D + g * G.no + rowo];
 
         // ---- A: my columns of q, k, v, straight from the previous frame's last LayerNorm ---------------------------------
-        const float bfq = tid < G.nq ? (i == 0 ? c.p.qkv0[g * G.nq + tid] : c.p.bf[(long long)phase * 3 * D + g * G.nq + tid] + img[G.ocq + tid])
-                                     : 0.f;
+        const float bfq = !pubq ? 0.f : i == 0 ? c.p.qkv0[g * G.nq + rowq] : c.p.bf[(long long)phase * 3 * D + g * G.nq + rowq];
         if (i == 0) {
-            if (tid < G.nq) publish(X + G.xq + g * G.nq + tid, bfq, tb + E_QKV);
+            if (pubq) publish(X + G.xq + g * G.nq + rowq, bfq, tb + E_QKV);
         } else {
             last_norm(i - 1);
-            const float qsum = gemv<BT>(img + G.oq, G.sq, rsq, G.nq, D, vec, 2 * D, red, 2, res);
-            if (tid < G.nq) publish(X + G.xq + g * G.nq + tid, qsum + bfq, tb + E_QKV);
+            float qs3[3];
+            gemv_rows<3>(img + G.oq, G.sq, rpq, G.nq, D, vec, qs3);
+            if (pubq) publish(X + G.xq + g * G.nq + rowq, (lane == 0 ? qs3[0] : lane == 1 ? qs3[1] : qs3[2]) + bfq + img[G.ocq + rowq], tb + E_QKV);
             if (mapr) emit_coeff(i - 1);
         }
         FFP_STAMP(1);       // q/k/v columns
@@ -434,27 +427,38 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                         mx[0] = fmaxf(mx[0], sco[p]);
                     }
                 }
-                block_reduce<1, true>(mx, red, 0);
-                float sum[1] = {0.f};
+                // softmax in ONE workgroup exchange: exponentials about the WAVE's maximum, (max, sum) of the four waves
+                // through LDS, the weights rescaled to the common maximum where they are used
+                const float mw = wave_max_u(mx[0]);
+                float sw = 0.f;
 #pragma unroll
                 for (int p = 0; p < KEYMAX / 64; ++p) {
                     const int n = p * 64 + n0;
                     if (n < nk && part == 0) {
-                        const float pj = __expf(sco[p] - mx[0]);
+                        const float pj = __expf(sco[p] - mw);
                         sc[n] = pj;
-                        sum[0] += pj;
+                        sw += pj;
                     }
                 }
-                block_reduce<1, false>(sum, red, 1);    // its barrier also publishes sc[] to every thread
+                sw = wave_sum_u(sw);
+                if ((tid & 63) == 0) red[0][tid >> 6] = mw, red[1][tid >> 6] = sw;
+                __syncthreads();                          // also publishes sc[] to every thread
+                mx[0] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+                float fw[4], sum[1] = {0.f};              // wave w's keys: weight exp(m_w - M)
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    fw[w4] = __expf(red[0][w4] - mx[0]);
+                    sum[0] = fmaf(fw[w4], red[1][w4], sum[0]);
+                }
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const int n = gk + u * groups;
-                    if (n < nk) a += sc[n] * (j0 + n * KSP == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l) : vpre[u]);
+                    if (n < nk) a += (sc[n] * fw[(n & 63) >> 4]) * (j0 + n * KSP == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l) : vpre[u]);
                 }
                 for (int n = gk + PF * groups; n < nk; n += groups) {
                     const int j = j0 + n * KSP;
-                    a += sc[n] * (j == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l)
+                    a += (sc[n] * fw[(n & 63) >> 4]) * (j == i ? *reinterpret_cast<const f32x4*>(vs + 4 * l)
                                          : *reinterpret_cast<const f32x4*>(kvb + (long long)j * 2 * D + D + hoff + 4 * l));
                 }
                 *reinterpret_cast<f32x4*>(accr + 4 * tid) = a;
@@ -476,6 +480,8 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         FFP_STAMP(2);       // attention (workgroups 0..15)
 
         // ---- C: merged attention, my rows of s1 = x + out_proj(att) ---------------------------------------------------
+        const unsigned long long* po = xbase + (long long)((i - 1) & 1) * G.xpar + G.xo + tid;   // o_{i-1}: requested now,
+        const unsigned long long go = (i > 0 && tid < BT * VP && !x.dead) ? peek(po) : 0ull;         // waited for below
         if (tid < BT * NATT * 2) {
             const int bb = tid / (NATT * 2), r = tid - bb * NATT * 2;
             const unsigned long long* p = X + G.xp + (long long)(bb * NATT + (r >> 1)) * G.ps + (r & 1);
@@ -517,20 +523,16 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                 }
         }
         if (tid < BT * VP) {                                                                     // [att | o_{i-1}]
-            float o = 0.f;
-            if (i > 0) {
-                const unsigned long long* p = xbase + (long long)((i - 1) & 1) * G.xpar + G.xo + tid;
-                o = settle(p, x.dead ? 0ull : peek(p), tb - NEDGE + E_O, x);
-            }
+            const float o = i > 0 ? settle(po, go, tb - NEDGE + E_O, x) : 0.f;
             vec[(tid / VP) * 2 * D + D + (tid % VP)] = o;
         }
         __syncthreads();
         FFP_STAMP(3);       // waited for the partials, merged them
-        const float osum = gemv<BT>(img + G.oo, G.so, rso, G.no, D + VP, vec, 2 * D, red, 2, res);
-        if (tid < BT * G.no) {
+        {
+            float os[1];
+            gemv_rows<1>(img + G.oo, G.so, rpo, G.no, D + VP, vec, os);
             // x = vertice_map(o_{i-1}) + pe_i (frame 0: obj_embedding + pe_0); the vertice_map product came out of the same rows
-            const int bb = tid >> rso;
-            publish(X + G.xs1 + (long long)bb * D + g * G.no + ro, osum + bias_o + pe_o, tb + E_S1);
+            if (pubo) publish(X + G.xs1 + g * G.no + rowo, os[0] + bias_o + pe_o, tb + E_S1);
         }
         FFP_STAMP(4);       // out-projection rows
 
@@ -539,33 +541,17 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             float t[BT][E];
             poll_regs<BT, E>(X + G.xs1, D, D, tb + E_S1, x, t);
             FFP_STAMP(5);   // waited for s1
-            const float invD = 1.f / D;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {          // LayerNorm 1 (+ cross), LayerNorm 2; two-pass statistics
-                float sm[BT], sq[BT];
+            for (int pass = 0; pass < 2; ++pass) {          // LayerNorm 1 (+ cross), LayerNorm 2
+                float mu[BT], rs[BT];
+                row_stats<BT, E>(t, D, red, 4 + pass * 4 * BT, mu, rs);
 #pragma unroll
-                for (int b = 0; b < BT; ++b) {
-                    sm[b] = 0.f;
-#pragma unroll
-                    for (int u = 0; u < E; ++u) sm[b] += t[b][u];           // columns past D hold 0
-                }
-                block_reduce<BT, false>(sm, red, 4 + pass * 2 * PB);
-#pragma unroll
-                for (int b = 0; b < BT; ++b) {
-                    sq[b] = 0.f;
-#pragma unroll
-                    for (int u = 0; u < E; ++u)
-                        if (u * NT + tid < D) sq[b] += (t[b][u] - sm[b] * invD) * (t[b][u] - sm[b] * invD);
-                }
-                block_reduce<BT, false>(sq, red, 4 + pass * 2 * PB + PB);
-#pragma unroll
-                for (int b = 0; b < BT; ++b) {
-                    const float mu = sm[b] * invD, rs = rsqrtf(sq[b] * invD + 1e-5f);
+                for (int b = 0; b < BT; ++b)
 #pragma unroll
                     for (int u = 0; u < E; ++u)
                         if (u * NT + tid < D)
-                            t[b][u] = pass == 0 ? (t[b][u] - mu) * rs * g1[u] + b1n[u] + crs[b][u] : (t[b][u] - mu) * rs * g2[u] + b2n[u];
-                }
+                            t[b][u] = pass == 0 ? (t[b][u] - mu[b]) * rs[b] * g1[u] + b1n[u] + crs[b][u]
+                                                : (t[b][u] - mu[b]) * rs[b] * g2[u] + b2n[u];
             }
 #pragma unroll
             for (int b = 0; b < BT; ++b)
@@ -575,11 +561,11 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             __syncthreads();
         }
         FFP_STAMP(6);       // two LayerNorms
-        const float x2own = tid < BT * G.n2 ? vec[(tid >> rs2) * 2 * D + g * G.n2 + r2] : 0.f;   // linear2's residual, my rows
-        const float hsum = gemv<BT>(img + G.o1, G.s1, rs1, G.n1, D, vec, 2 * D, red, 2, res);
-        if (tid < BT * G.n1) {
-            const int bb = tid >> rs1;
-            publish(X + G.xh + (long long)bb * 2 * D + g * G.n1 + r1, fmaxf(hsum + bias_1, 0.f), tb + E_H);
+        const float x2own = pub2 ? vec[g * G.n2 + row2] : 0.f;       // linear2's residual, my rows
+        {
+            float hs2[2];
+            gemv_rows<2>(img + G.o1, G.s1, rp1, G.n1, D, vec, hs2);
+            if (pub1) publish(X + G.xh + g * G.n1 + row1, fmaxf((lane == 0 ? hs2[0] : hs2[1]) + bias_1, 0.f), tb + E_H);
         }
         FFP_STAMP(7);       // linear1 rows
 
@@ -587,6 +573,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         {
             float t[BT][2 * E];
             poll_regs<BT, 2 * E>(X + G.xh, 2 * D, 2 * D, tb + E_H, x, t);
+            __syncthreads();            // every wave is done with x2 in vec (linear1 has no barrier of its own)
 #pragma unroll
             for (int b = 0; b < BT; ++b)
 #pragma unroll
@@ -595,10 +582,10 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             __syncthreads();
         }
         FFP_STAMP(8);       // waited for h
-        const float ssum = gemv<BT>(img + G.o2, G.s2, rs2, G.n2, 2 * D, vec, 2 * D, red, 2, res);
-        if (tid < BT * G.n2) {
-            const int bb = tid >> rs2;
-            publish(X + G.xs3 + (long long)bb * D + g * G.n2 + r2, x2own + bias_2 + ssum, tb + E_S3);
+        {
+            float ss[1];
+            gemv_rows<1>(img + G.o2, G.s2, rp2, G.n2, 2 * D, vec, ss);
+            if (pub2) publish(X + G.xs3 + g * G.n2 + row2, x2own + bias_2 + ss[0], tb + E_S3);
         }
         FFP_STAMP(9);       // linear2 rows
 

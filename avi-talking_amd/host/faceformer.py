@@ -214,7 +214,9 @@ class Faceformer:
         if self.use_steps:
             if self.use_persist and not no_persist and B == 1 and 6 * T + 6 < 65535 and chunk <= 1024:
                 return self._decode_persistent(cross, B, T, chunk, out_dtype=out_dtype)
+            self._last_path = "steps"
             return self._decode_steps(cross, B, T, chunk, out_dtype=out_dtype)
+        self._last_path = "single"
         kv = torch.empty((B, T, 2 * D), dtype=torch.float32, device=self.device)
         out = torch.empty((B, T, self.V), dtype=out_dtype, device=self.device)
         fn = L.load().avi_faceformer_decode_chunked_f16 if out_dtype == torch.float16 else L.load().avi_faceformer_decode_chunked

@@ -1183,8 +1183,7 @@ def measure_faceformer(dev, reps=5):
             torch.cuda.synchronize(dev)
             ms = min(a.elapsed_time(b) for a, b in evs)
             wbytes = (8 * D * D + 2 * 53 * D) * 4                        # fp32 weights of one frame step (qkv, out, ff1, ff2, maps)
-            path = ("one workgroup per utterance" if not m.use_steps else
-                    "persistent launch" if any(k[0] == "persist" for k in m._graphs) else "launch chain")
+            path = {"single": "one workgroup per utterance", "steps": "launch chain", "persist": "persistent launch"}[m._last_path]
             out["cases"].append({"D": D, "utterances": B, "path": path, "ms": round(ms, 3),
                                  "frames_per_s": round(B * T_FRAMES / ms * 1e3, 1),
                                  "us_per_frame_step": round(ms * 1e3 / T_FRAMES, 2),
