@@ -401,10 +401,19 @@ def measure_flame(dev, reps=10):
     torch.cuda.synchronize(dev)
     dt = min(a.elapsed_time(b) for a, b in evs) * 1e-3
     nbytes = v.numel() * 4
+    traffic = None
+    tp = latest_profile("pmc_flame_traffic.json")       # rocprofv3 FETCH_SIZE / WRITE_SIZE passes over scripts/time_flame_mc.py
+    if tp:
+        with open(tp) as fh:
+            ks = json.load(fh).get("kernels", {})
+        parts = [x["hbm_bytes_per_launch"] for k, x in ks.items() if k.startswith(("flame_vertices", "flame_prep"))]
+        traffic = int(sum(parts)) if parts else None
     return {"workload": "FLAME LBS vertices, 32 clips x 250 frames x 5023 vertices (synthetic basis)",
             "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(B_CLIPS * T_FRAMES / dt, 1),
             "roofline": {"bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(nbytes / dt / 8e12, 4)}}
+                         "frac": round(nbytes / dt / 8e12, 4), "algorithmic_bytes": nbytes, "traffic": traffic,
+                         "traffic_note": "HBM-side bytes of the pass's two launches from the PMC passes (profiles/): the output "
+                                         "plus the basis fragments fetched again for every clip (they do not fit an XCD's L2)"}}
 
 
 def measure_clip_text(dev, reps=10):
