@@ -225,3 +225,24 @@ def test_persistent_decode_fails_loudly_and_falls_back(gpu):
     again = ff.decode_checked(hs.to(gpu))            # the fault is gone: the persistent launch answers by itself
     assert ff.last_fallback is None and torch.equal(again, good) is False or True
     assert (again.cpu() - good.cpu()).abs().max().item() < 1e-4
+
+
+def test_persistent_decode_long_chunked_window_matches_launch_chain(gpu):
+    """Long form on the persistent launch: T = 1300 with the 600-frame window (a key residue holds up to 150 keys: three
+    score passes, values beyond the prefetched ones loaded on demand), against the launch chain that the oracle pins."""
+    from avi_talking_amd.weights import make_faceformer_weights
+    from avi_talking_amd.host.faceformer import Faceformer
+    from avi_talking_amd.host import status
+    ff = Faceformer(make_faceformer_weights(2, feature_dim=512), period=30, device=gpu)
+    if not ff.use_persist:
+        pytest.skip("the persistent decode needs a device with 256 CUs")
+    status.clear()
+    hs = torch.randn(1, 1300, 512, generator=torch.Generator().manual_seed(64)).to(gpu)
+    out = ff.decode(hs, chunk=600)
+    chain = ff.decode(hs, chunk=600, no_persist=True)
+    torch.cuda.synchronize()
+    assert ff._last_path == "steps" and any(k[0] == "persist" for k in ff._graphs)
+    d = (out - chain).abs().max().item()
+    print(f"persistent vs launch chain, T=1300 chunk=600: {d:.2e}")
+    assert torch.isfinite(out).all() and d < 1e-4
+    status.raise_if_set()
