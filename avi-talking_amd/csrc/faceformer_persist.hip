@@ -1,11 +1,11 @@
-// FaceFormer autoregressive decode for WIDE decoders and SMALL batches as ONE persistent launch
+// FaceFormer autoregressive decode for WIDE decoders, ONE utterance, as ONE persistent launch
 // (avi_faceformer_decode_persistent; models/faceformer.py:710-729 = `predict`'s loop, KV-cached as in faceformer_steps.hip).
 //
 // faceformer_steps.hip cuts a frame into 6 launches.  At B = 1 each of them lasts 5-10 us although it moves a few hundred
 // KB: a launch starts with cold L2s (the XCDs' L2s are written back / invalidated at kernel boundaries), so every launch
 // re-fetches its weight slice through the fabric, then waits for its inputs, then drains - 40 us per frame for 22 MB of
 // weights that never change.  Here the weights never move: 256 workgroups, one per CU (the launch needs all 256 CUs of an
-// MI355X free: 133 KB of LDS each), and workgroup g keeps ITS rows of every matrix in LDS for the whole decode, in fp32:
+// MI355X free: 157 KB of LDS each at D = 1024), and workgroup g keeps ITS rows of every matrix in LDS for the whole decode, in fp32:
 //     q/k/v from LN3's output  3D/256 rows x D  (in_proj . vertice_map . vertice_map_r folded into one matrix: the next
 //                              frame's q, k, v straight from this frame's last LayerNorm, not through the 53 coefficients)
 //     out_proj | vertice_map   D/256 rows x (D + 64)        linear1  2D/256 rows x D        linear2  D/256 rows x 2D
@@ -24,7 +24,9 @@
 // Every spin is bounded: a workgroup that never sees a granule (the launch did not get all its CUs, a foreign kernel holds
 // one) gives up ONCE, takes NaN from then on - so does everything downstream, with correct tags, nobody else stalls - and
 // raises AVI_STATUS_EXCHANGE_TIMEOUT; the launch always drains.  Arithmetic: fp32 multiply-adds on fp32 weights (the launch
-// chain's 3-term bf16 products agree to ~1e-6); LayerNorms two-pass.
+// chain's 3-term bf16 products agree to ~1e-6); LayerNorm statistics from per-thread (n, mean, M2) triples merged in one
+// workgroup reduction (row_stats).  Rows of a matrix belong to WAVES (gemv_rows): the matrix-vector products need neither LDS
+// traffic for partial sums nor barriers.
 #include "common.h"
 
 namespace {
