@@ -1198,6 +1198,8 @@ def measure_faceformer(dev, reps=5):
                                  "us_per_frame_step": round(ms * 1e3 / T_FRAMES, 2),
                                  "weight_bytes_per_step": wbytes,
                                  "weight_stream_gbps_per_utterance": round(wbytes * T_FRAMES / ms / 1e6, 1)})
+    from avi_talking_amd.host import status
+    status.raise_if_set()       # a persistent decode that timed out on an exchange would have returned NaN: not a measurement
     return out
 
 
