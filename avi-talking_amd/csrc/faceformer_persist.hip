@@ -112,6 +112,37 @@ __device__ __forceinline__ float settle(const unsigned long long* p, unsigned lo
     }
     return x.dead ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)gr);
 }
+// Several granules of one thread: every one of gr[idx] (idx < N, bit idx of `want` set; gr = what a first look saw, addr(idx) its
+// address) is looked at until it carries `tag` - ALL the missing ones together in every round.  One after the other (settle on
+// each in turn) a thread pays a full round trip through the fabric for every granule whose FIRST look came too early, and the
+// first looks are all taken right after the thread's own publish: up to N round trips per wait instead of one or two.
+template <int N, typename F>
+__device__ __forceinline__ void settle_all(F addr, unsigned long long (&gr)[N], unsigned want, unsigned tag, Ex& x) {
+    unsigned pending = 0;
+#pragma unroll
+    for (int idx = 0; idx < N; ++idx)
+        if (((want >> idx) & 1u) && (unsigned)(gr[idx] >> 32) != tag) pending |= 1u << idx;
+    unsigned spins = 0;
+    while (pending && !x.dead) {
+        if (++spins > SPIN_LIMIT) {
+            if (x.status) __hip_atomic_store(x.status + AVI_STATUS_EXCHANGE_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *x.wg_dead = 1;
+            x.dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int idx = 0; idx < N; ++idx)
+            if ((pending >> idx) & 1u) gr[idx] = peek(addr(idx));
+#pragma unroll
+        for (int idx = 0; idx < N; ++idx)
+            if (((pending >> idx) & 1u) && (unsigned)(gr[idx] >> 32) == tag) pending &= ~(1u << idx);
+    }
+}
+__device__ __forceinline__ float granule_value(unsigned long long gr, const Ex& x) {
+    return x.dead ? __builtin_nanf("") : __builtin_bit_cast(float, (unsigned)gr);
+}
+
 // ---- small reductions on DPP lanes (a ds_bpermute round trip costs ~100 cycles; these are 2-7 vector instructions) ----
 #define FFP_DPP(x, ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rm, 0xF, false))
 // sum over each aligned group of 4 lanes, in all 4
@@ -181,21 +212,18 @@ __device__ __forceinline__ void row_stats(const float (&t)[BT][E], int D, float 
 template <int BT, int E>
 __device__ __forceinline__ void poll_regs(const unsigned long long* src, long long stride, int n, unsigned tag, Ex& x,
                                           float (&v)[BT][E]) {
-    unsigned long long gr[BT][E];
+    unsigned long long gr[BT * E];
+    unsigned want = 0;
+    auto addr = [&](int idx) __attribute__((always_inline)) { return src + (idx / E) * stride + (idx % E) * NT + threadIdx.x; };
 #pragma unroll
-    for (int b = 0; b < BT; ++b)
+    for (int idx = 0; idx < BT * E; ++idx) {
+        const bool on = (idx % E) * NT + (int)threadIdx.x < n;
+        if (on) want |= 1u << idx;
+        gr[idx] = (on && !x.dead) ? peek(addr(idx)) : 0ull;
+    }
+    settle_all<BT * E>(addr, gr, want, tag, x);
 #pragma unroll
-        for (int u = 0; u < E; ++u) {
-            const int k = u * NT + threadIdx.x;
-            gr[b][u] = (k < n && !x.dead) ? peek(src + b * stride + k) : 0ull;
-        }
-#pragma unroll
-    for (int b = 0; b < BT; ++b)
-#pragma unroll
-        for (int u = 0; u < E; ++u) {
-            const int k = u * NT + threadIdx.x;
-            v[b][u] = k < n ? settle(src + b * stride + k, gr[b][u], tag, x) : 0.f;
-        }
+    for (int idx = 0; idx < BT * E; ++idx) v[idx / E][idx % E] = ((want >> idx) & 1u) ? granule_value(gr[idx], x) : 0.f;
 }
 
 // sums[q] = sum_k W[(wave * rpw + q) * ws + k] x[k] for q < rpw <= RPW: wave w owns rows w rpw .. w rpw + rpw - 1 (rows >= nrow
@@ -398,10 +426,12 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                     unsigned long long gr[3];
 #pragma unroll
                     for (int w3 = 0; w3 < 3; ++w3) gr[w3] = (w3 < nw && tid < dh && !x.dead) ? peek(Xq + w3 * D + tid) : 0ull;
+                    settle_all<3>([&](int w3) __attribute__((always_inline)) { return Xq + w3 * D + tid; }, gr,
+                                  tid < dh ? (nw == 3 ? 7u : 1u) : 0u, tb + E_QKV, x);
 #pragma unroll
                     for (int w3 = 0; w3 < 3; ++w3)
                         if (w3 < nw && tid < dh) {
-                            const float v = settle(Xq + w3 * D + tid, gr[w3], tb + E_QKV, x);
+                            const float v = granule_value(gr[w3], x);
                             (w3 == 0 ? qs : w3 == 1 ? ks : vs)[tid] = v;
                             if (w3 > 0) kvb[(long long)i * 2 * D + (w3 - 1) * D + hoff + tid] = v;
                         }
@@ -495,22 +525,25 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
         }
         {
             // the accumulators of my E columns: requested before the (m, l) pairs are waited for
-            unsigned long long gr[BT][E][KSP];
+            unsigned long long gr[E * KSP];             // (column u, key residue s) -> u * KSP + s; BT == 1
+            auto addr = [&](int idx) __attribute__((always_inline)) {
+                const int d = (idx / KSP) * NT + tid, h = d >> dsh, dd = d & (dh - 1);
+                return X + G.xp + (long long)(h * KSP + idx % KSP) * G.ps + 4 + dd;
+            };
+            unsigned want = 0;
 #pragma unroll
-            for (int b = 0; b < BT; ++b)
-#pragma unroll
-                for (int u = 0; u < E; ++u) {
-                    const int d = u * NT + tid, h = d >> dsh, dd = d & (dh - 1);
-#pragma unroll
-                    for (int s = 0; s < KSP; ++s)
-                        gr[b][u][s] = (d < D && !x.dead) ? peek(X + G.xp + (long long)(b * NATT + h * KSP + s) * G.ps + 4 + dd) : 0ull;
-                }
+            for (int idx = 0; idx < E * KSP; ++idx) {
+                const bool on = (idx / KSP) * NT + tid < D;
+                if (on) want |= 1u << idx;
+                gr[idx] = (on && !x.dead) ? peek(addr(idx)) : 0ull;
+            }
+            settle_all<E * KSP>(addr, gr, want, tb + E_PART, x);
             __syncthreads();
 #pragma unroll
             for (int b = 0; b < BT; ++b)
 #pragma unroll
                 for (int u = 0; u < E; ++u) {
-                    const int d = u * NT + tid, h = d >> dsh, dd = d & (dh - 1);
+                    const int d = u * NT + tid, h = d >> dsh;
                     if (d < D) {
                         const float* mlh = ml + (b * NATT + h * KSP) * 2;
                         float M = -3.0e38f;
@@ -521,8 +554,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                         for (int s = 0; s < KSP; ++s) {
                             const float wgt = __expf(mlh[2 * s] - M);
                             L = fmaf(wgt, mlh[2 * s + 1], L);
-                            r = fmaf(wgt, settle(X + G.xp + (long long)(b * NATT + h * KSP + s) * G.ps + 4 + dd, gr[b][u][s],
-                                                 tb + E_PART, x), r);
+                            r = fmaf(wgt, granule_value(gr[u * KSP + s], x), r);
                         }
                         vec[b * 2 * D + d] = r / L;
                     }
