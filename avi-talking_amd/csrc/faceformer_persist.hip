@@ -437,6 +437,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                         }
                 }
                 __syncthreads();
+                FFP_STAMP(10);
                 // scores of keys n = 64 p + tid / 4; pass 0 from the prefetched rows
                 float sco[KEYMAX / 64], mx[1] = {-3.0e38f};
 #pragma unroll
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                 sw = wave_sum_u(sw);
                 if ((tid & 63) == 0) red[0][tid >> 6] = mw, red[1][tid >> 6] = sw;
                 __syncthreads();                          // also publishes sc[] to every thread
+                FFP_STAMP(11);
                 mx[0] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
                 float fw[4], sum[1] = {0.f};              // wave w's keys: weight exp(m_w - M)
 #pragma unroll
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
                 }
                 *reinterpret_cast<f32x4*>(accr + 4 * tid) = a;
                 __syncthreads();
+                FFP_STAMP(12);
                 unsigned long long* Xp = X + G.xp + (long long)(b * NATT + g) * G.ps;
                 if (tid < dh) {
                     const int lq = tid >> 2, comp = tid & 3;
