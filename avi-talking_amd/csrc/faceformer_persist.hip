@@ -116,6 +116,8 @@ __device__ __forceinline__ float settle(const unsigned long long* p, unsigned lo
 // address) is looked at until it carries `tag` - ALL the missing ones together in every round.  One after the other (settle on
 // each in turn) a thread pays a full round trip through the fabric for every granule whose FIRST look came too early, and the
 // first looks are all taken right after the thread's own publish: up to N round trips per wait instead of one or two.
+// (Two generations of looks in flight half a beat apart - to see a granule sooner after it becomes visible - measured
+// SLOWER: 23.4 vs 21.9 us per frame at D = 1024, 22.8 vs 19.8 at D = 256: twice the polling traffic on the same fabric.)
 template <int N, typename F>
 __device__ __forceinline__ void settle_all(F addr, unsigned long long (&gr)[N], unsigned want, unsigned tag, Ex& x) {
     unsigned pending = 0;
@@ -256,8 +258,8 @@ __device__ __forceinline__ void gemv_rows(const float* __restrict__ W, int ws, i
     for (int q = 0; q < RPW; ++q) sums[q] = q < rpw ? wave_sum_u(a[q]) : 0.f;
 }
 
-// AVI_FFP_STAMPS (diagnostic build, scripts/ffp_stamps.py): thread 0 of workgroups 0 and 200 adds up the time (100 MHz ticks)
-// between the marks below over all frames; at the end the sums overwrite the first floats of the output.
+// AVI_FFP_STAMPS (diagnostic build, scripts/ffp_stamps.py): thread 0 of workgroups 0, 13, 70 and 200 adds up the time (100 MHz
+// ticks) between the marks below over all frames; at the end the sums overwrite the first floats of the output.
 #ifdef AVI_FFP_STAMPS
 #define FFP_STAMP(k)                                         \
     do {                                                     \
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
             // normalised: what vertice_map feeds back (:722-725)
             publish(xbase + (long long)(f & 1) * G.xpar + G.xo + (long long)tid * VP + gm, v, ((epoch << 16) | (unsigned)(f * NEDGE + 1)) + E_O);
 #ifdef AVI_FFP_STAMPS
-            if (real && f > 0) {       // frame 0's slots of the output carry the stamps in this build
+            if (real && f > 1) {       // the first two frames' slots of the output carry the stamps in this build
 #else
             if (real) {
 #endif
@@ -637,8 +639,8 @@ __global__ __launch_bounds__(NT) void ff_persist_kernel(const Persist c) {
     }
 #ifdef AVI_FFP_STAMPS
     __syncthreads();
-    if (tid == 0 && (g == 0 || g == 200) && c.out)
-        for (int k = 0; k < 16; ++k) c.out[(g == 0 ? 0 : 16) + k] = (float)stamp_acc[k];
+    if (tid == 0 && (g == 0 || g == 200 || g == 13 || g == 70) && c.out)      // attention, plain, attention, coefficient workgroup
+        for (int k = 0; k < 16; ++k) c.out[(g == 0 ? 0 : g == 200 ? 16 : g == 13 ? 32 : 48) + k] = (float)stamp_acc[k];
 #endif
 }
 

@@ -18,11 +18,11 @@ hs = torch.randn(B, T, D, device=dev)
 m.decode(hs)
 out = m.decode(hs)
 torch.cuda.synchronize()
-v = out.reshape(-1)[:32].cpu().tolist()
+v = out.reshape(-1)[:64].cpu().tolist()
 names = ["wait s3 (prev frame)", "LN3 + q/k/v rows", "attention", "wait+merge partials, o", "out-proj rows", "wait s1",
          "LayerNorm 1+2", "linear1 rows", "wait h", "linear2 rows", "  attention: wait q/k/v", "  attention: scores + softmax",
          "  attention: P.V"]
-for wg, base in ((0, 0), (200, 16)):
+for wg, base in ((0, 0), (13, 32), (70, 48), (200, 16)):
     tot = sum(v[base:base + 13])
     print(f"workgroup {wg}: {tot / 100 / T:.2f} us per frame")
     for k, n in enumerate(names):
